@@ -1,0 +1,153 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz from the REAL reference (container only).
+
+Run ``python oracle/gen_golden.py`` in the build container (``/root/reference`` present).  The fixtures are
+data only: seeded inputs, explicit weights and the outputs the reference's own code produced for them.
+The reference has no tests / golden vectors of its own, so these are the pins for the
+CPU restatement ``oracle/sunerf_oracle.py`` and, through it, for the HIP path.
+
+Fixtures:
+  g1_sampler        StratifiedSampler / SphericalSampler z_vals + points (hit and miss rays, perturb via
+                    a recorded t_rand)
+  g2_mlp            PositionalEncoding + NeRF(d_filter=64) on 256 points: enc, inferences
+  g3_integral       EmissionRadiativeTransfer.raw2outputs on random raw: image, weights, absorption
+  g4_hierarchical   HierarchicalSampler on g3's weights: new_z_samples, z_vals_combined
+  g5_emission_e2e   shimmed two-pass emission forward: all 8 outputs + training loss (sunerf.py:110-120)
+                    + gradients of every parameter, d_filter=64
+  g5b_emission_d256 same at d_filter=256 (weights stored), forward outputs + loss only
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+import sunerf_oracle as orc  # noqa: E402  (only for the synthetic ray generator)
+
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+
+
+def npz(name, **arrays):
+    arrays = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **arrays)
+    print(name, {k: v.shape for k, v in arrays.items()})
+
+
+def test_rays(n_side, seed):
+    """A mix of rays that hit the disk and rays that traverse the full slab, non-unit directions."""
+    o, d = orc.synthetic_rays(n_side)
+    g = torch.Generator().manual_seed(seed)
+    d = d * (0.8 + 0.4 * torch.rand(d.shape[0], 1, generator=g))  # non-unit |d| exercises dists*|d|
+    t = torch.rand(d.shape[0], 1, generator=g)
+    return o.contiguous(), d.contiguous(), t
+
+
+def state_arrays(prefix, module):
+    return {prefix + k.replace('.', '__'): v for k, v in module.state_dict().items()}
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(7)
+    torch.set_num_threads(1)
+    ref = ref_import.import_reference()
+    S = ref.train.sampling
+    M = ref.model.model
+    Emission = ref_import.shimmed_emission_class()
+
+    # ---- G1 samplers
+    o, d, t = test_rays(8, 1)
+    st = S.StratifiedSampler(Rs_per_ds=1.0, distance=1.3, n_samples=32, perturb=False)
+    out = st(o, d)
+    sp = S.SphericalSampler(Rs_per_ds=1.0, distance=2.0, n_samples=32, perturb=False)
+    # spherical needs rays that cross the 2 Rs sphere: tighter field of view
+    o2, d2 = orc.synthetic_rays(8, fov_half_rad=0.4 * 960. / 206264.806 * 2.0)
+    out_sp = sp(o2, d2)
+    # perturb=True with a recorded t_rand: monkeypatch torch.rand for the call
+    t_rand = torch.rand(64, 32, generator=torch.Generator().manual_seed(3))
+    st_p = S.StratifiedSampler(Rs_per_ds=1.0, distance=1.3, n_samples=32, perturb=True)
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: t_rand
+    try:
+        out_p = st_p(o, d)
+    finally:
+        torch.rand = real_rand
+    st_rs = S.StratifiedSampler(Rs_per_ds=0.5, distance=1.3, n_samples=16, perturb=False)
+    out_rs = st_rs(o * 2, d)  # Rs_per_ds != 1: lengths in units of 2 solar radii... origin scaled to match
+    npz('g1_sampler', rays_o=o, rays_d=d, t_vals=st.t_vals, z_vals=out['z_vals'], points=out['points'],
+        rays_o_sph=o2, rays_d_sph=d2, z_vals_sph=out_sp['z_vals'], points_sph=out_sp['points'],
+        t_rand=t_rand, z_vals_perturb=out_p['z_vals'],
+        rays_o_rs=o * 2, t_vals_rs=st_rs.t_vals, z_vals_rs=out_rs['z_vals'])
+
+    # ---- G2 encoder + MLP
+    torch.manual_seed(7)
+    net = M.NeRF(d_input=4, d_output=2, n_layers=8, d_filter=64)
+    x = torch.cat([torch.randn(256, 3) * 1.2, torch.rand(256, 1) * 30.], -1)
+    enc = net.in_layer[0](x)
+    inf = net(x)['inferences']
+    npz('g2_mlp', x=x, enc=enc, inferences=inf, **state_arrays('net__', net))
+
+    # ---- G3 emission integral on random raw
+    g = torch.Generator().manual_seed(11)
+    raw = torch.randn(64, 32, 2, generator=g)
+    raw.requires_grad_(True)
+    em = Emission(Rs_per_ds=1.0, sampling_config={'type': 'stratified', 'n_samples': 32, 'perturb': False},
+                  hierarchical_sampling_config={'type': 'hierarchical', 'n_samples': 32},
+                  model_config={'d_filter': 64})
+    r = em.raw2outputs(raw=raw, z_vals=out['z_vals'], rays_d=d)
+    gw = torch.randn(64, 32, generator=g)
+    (r['image'].sum() + (r['weights'] * gw).sum()).backward()
+    npz('g3_integral', raw=raw, z_vals=out['z_vals'], rays_d=d, image=r['image'], weights=r['weights'],
+        absorption=r['regularizing_quantity'], grad_probe=gw, grad_raw=raw.grad)
+
+    # ---- G4 hierarchical sampler
+    hs = S.HierarchicalSampler(n_samples=32, perturb=False)
+    h = hs(o, d, out['z_vals'], r['weights'].detach())
+    hs48 = S.HierarchicalSampler(n_samples=48, perturb=False)
+    h48 = hs48(o, d, out['z_vals'], r['weights'].detach())
+    # degenerate: all-zero weights (uniform pdf) and a one-hot weight row
+    wdeg = torch.zeros(4, 32)
+    wdeg[1, 7] = 1.0
+    wdeg[2, 1] = 0.5
+    wdeg[2, 30] = 0.5
+    wdeg[3] = 1.0 / 32
+    hdeg = hs(o[:4], d[:4], out['z_vals'][:4], wdeg)
+    npz('g4_hierarchical', z_vals=out['z_vals'], weights=r['weights'], new_z=h['new_z_samples'],
+        z_comb=h['z_vals'], new_z48=h48['new_z_samples'], z_comb48=h48['z_vals'],
+        weights_deg=wdeg, new_z_deg=hdeg['new_z_samples'], z_comb_deg=hdeg['z_vals'])
+
+    # ---- G5 end-to-end emission (d_filter=64) with loss and grads
+    def e2e(name, d_filter, n_side, n_c, n_f, with_grads):
+        torch.manual_seed(7)
+        mod = Emission(Rs_per_ds=1.0,
+                       sampling_config={'type': 'stratified', 'n_samples': n_c, 'perturb': False},
+                       hierarchical_sampling_config={'type': 'hierarchical', 'n_samples': n_f},
+                       model_config={'d_filter': d_filter})
+        o, d, t = test_rays(n_side, 5)
+        outputs = mod(o, d, t)
+        target = torch.rand(o.shape[0], 1, generator=torch.Generator().manual_seed(1))
+        scaling = ref.train.scaling.ImageAsinhScaling(vmax=1, a=0.005)
+        mse = torch.nn.MSELoss()
+        tgt = scaling(target)
+        coarse_loss = mse(scaling(outputs['coarse_image']), tgt)
+        fine_loss = mse(scaling(outputs['fine_image']), tgt)
+        reg = outputs['regularization'].mean()
+        loss = 1.0 * (coarse_loss + fine_loss) + 1.0 * reg
+        arrays = dict(rays_o=o, rays_d=d, times=t, target=target, loss=loss, coarse_loss=coarse_loss,
+                      fine_loss=fine_loss, reg_loss=reg, t_vals=mod.sampler.t_vals)
+        arrays.update({'out__' + k: v for k, v in outputs.items()})
+        arrays.update(state_arrays('sd__', mod))
+        if with_grads:
+            loss.backward()
+            arrays.update({'grad__' + k.replace('.', '__'): p.grad for k, p in mod.named_parameters()})
+        npz(name, **arrays)
+
+    e2e('g5_emission_e2e', 64, 6, 32, 32, True)
+    e2e('g5b_emission_d256', 256, 4, 32, 64, False)
+    ref_import.release_reference()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,115 @@
+"""Pins the CPU restatement (oracle/sunerf_oracle.py) against golden vectors produced by the REAL reference
+(oracle/gen_golden.py).  Runs on CPU, no GPU needed.  Tolerance: bit-exact wherever the aten op sequence is the
+same; 1e-6 rel otherwise (stated per test)."""
+import torch
+
+import sunerf_oracle as orc
+from conftest import load_golden, params_from_golden
+
+
+def exact(a, b):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    same = torch.equal(torch.nan_to_num(a, nan=123.), torch.nan_to_num(b, nan=123.))
+    assert same, f'max abs diff {(a - b).abs().max().item():.3e}'
+
+
+def close(a, b, rel=1e-5):
+    """relative to the tensor's scale: |a-b|_inf <= rel * |b|_inf"""
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    assert err <= rel * b.abs().max().item(), f'max abs diff {err:.3e} vs scale {b.abs().max().item():.3e}'
+
+
+def test_g1_stratified_sampler_bit_exact():
+    g = load_golden('g1_sampler')
+    z = orc.stratified_z(g['rays_o'], g['rays_d'], g['t_vals'], torch.tensor(1.3), torch.tensor(1.0))
+    exact(z, g['z_vals'])
+    exact(orc.points_on_rays(g['rays_o'], g['rays_d'], z), g['points'])
+    assert torch.equal(orc.linspace_t_vals(32), g['t_vals'])
+    zp = orc.stratified_z(g['rays_o'], g['rays_d'], g['t_vals'], torch.tensor(1.3), torch.tensor(1.0), g['t_rand'])
+    exact(zp, g['z_vals_perturb'])
+    zr = orc.stratified_z(g['rays_o_rs'], g['rays_d'], g['t_vals_rs'],
+                          torch.tensor(1.3 / 0.5, dtype=torch.float32), torch.tensor(1 / 0.5, dtype=torch.float32))
+    exact(zr, g['z_vals_rs'])
+
+
+def test_g1_spherical_sampler_bit_exact():
+    g = load_golden('g1_sampler')
+    z = orc.spherical_z(g['rays_o_sph'], g['rays_d_sph'], g['t_vals'], torch.tensor(2.0), torch.tensor(1.0))
+    exact(z, g['z_vals_sph'])
+    assert torch.isfinite(z).all()
+
+
+def test_g2_encoding_and_mlp_bit_exact():
+    g = load_golden('g2_mlp')
+    exact(orc.positional_encoding(g['x']), g['enc'])
+    params = params_from_golden(g, 'net__')
+    exact(orc.mlp_forward(params, g['x']), g['inferences'])
+
+
+def test_g3_emission_integral_and_grad():
+    g = load_golden('g3_integral')
+    raw = g['raw'].clone().requires_grad_(True)
+    r = orc.emission_integral(raw, g['z_vals'], g['rays_d'])
+    exact(r['image'], g['image'])
+    exact(r['weights'], g['weights'])
+    exact(r['regularizing_quantity'], g['absorption'])
+    (r['image'].sum() + (r['weights'] * g['grad_probe']).sum()).backward()
+    exact(raw.grad, g['grad_raw'])
+
+
+def test_g4_hierarchical_bit_exact():
+    g = load_golden('g4_hierarchical')
+    nz, zc = orc.hierarchical_z(g['z_vals'], g['weights'], 32)
+    exact(nz, g['new_z'])
+    exact(zc, g['z_comb'])
+    nz, zc = orc.hierarchical_z(g['z_vals'], g['weights'], 48)
+    exact(nz, g['new_z48'])
+    exact(zc, g['z_comb48'])
+    nz, zc = orc.hierarchical_z(g['z_vals'][:4], g['weights_deg'], 32)
+    exact(nz, g['new_z_deg'])
+    exact(zc, g['z_comb_deg'])
+
+
+def _e2e(name, n_c, n_f):
+    g = load_golden(name)
+    coarse = params_from_golden(g, 'sd__coarse_model__')
+    fine = params_from_golden(g, 'sd__fine_model__')
+    for W, b in coarse + fine:
+        W.requires_grad_(True)
+        b.requires_grad_(True)
+    out = orc.render_emission(coarse, fine, g['rays_o'], g['rays_d'], g['times'], Rs_per_ds=1.0,
+                              n_coarse=n_c, n_fine=n_f, t_vals=g['t_vals'])
+    for k in ['z_vals_stratified', 'coarse_image', 'z_vals_hierarchical', 'fine_image', 'image', 'height_map',
+              'absorption_map', 'regularization']:
+        exact(out[k], g['out__' + k])
+    loss = orc.emission_training_loss(out, g['target'])
+    exact(loss['loss'], g['loss'])
+    exact(loss['coarse'], g['coarse_loss'])
+    exact(loss['fine'], g['fine_loss'])
+    exact(loss['regularization'], g['reg_loss'])
+    return g, coarse, fine, loss
+
+
+def test_g5_end_to_end_outputs_loss_and_grads():
+    g, coarse, fine, loss = _e2e('g5_emission_e2e', 32, 32)
+    loss['loss'].backward()
+    names = ['in_layer__1'] + [f'layers__{i}' for i in range(7)] + ['out_layer']
+    for tag, params in (('coarse_model', coarse), ('fine_model', fine)):
+        for n, (W, b) in zip(names, params):
+            # backward GEMM blocking depends on the thread count => 1e-5 of the tensor's scale, not bit-exact
+            close(W.grad, g[f'grad__{tag}__{n}__weight'])
+            close(b.grad, g[f'grad__{tag}__{n}__bias'])
+
+
+def test_g5b_end_to_end_d256():
+    _e2e('g5b_emission_d256', 32, 64)
+
+
+def test_synthetic_rays_hit_fraction():
+    o, d = orc.synthetic_rays(64)
+    z = orc.stratified_z(o, d, orc.linspace_t_vals(32), torch.tensor(1.3), torch.tensor(1.0))
+    hit = (z[:, -1] < (o.norm(dim=-1) + 1.2)).float().mean().item()
+    assert 0.55 < hit < 0.75      # ~ pi/2.2^2 of the field of view is on disk
+    assert torch.isfinite(z).all()
+    assert abs(d.norm(dim=-1).mean().item() - 1.0) < 1e-5
