@@ -1,0 +1,76 @@
+// Shared definitions of the gfx950 SuNeRF renderer kernels (device + host).
+//
+// Packed MLP image (produced by pack.hip, consumed by render_fwd.hip / render_bwd.hip)
+// ----------------------------------------------------------------------------------
+// The field MLP of the reference (NeRF, sunerf/model/model.py:12-57) is evaluated TRANSPOSED on the
+// matrix cores:  H_{l+1}^T = W_l * H_l^T  with  A = W_l (rows = output features),  B = H_l^T (columns =
+// samples), v_mfma_f32_32x32x16_f16.  With that orientation the 32x32 fp32 accumulator tile of layer l
+// (column = sample on the lane, rows = features in the 16 registers) IS, after sin() and conversion to
+// fp16, the B operand of layer l+1 -- activations never leave the register file.
+//
+// fp32 accuracy on fp16 matrix cores: every operand x is split x = hi + lo (both fp16, |x-hi-lo| <= 2^-22 |x|,
+// fp16 subnormals are honoured by the MFMA on gfx950) and a product is formed from three MFMAs
+// (hi*hi + hi*lo + lo*hi, fp32 accumulate).  That is 3/16 of the cost of the exact-fp32 MFMA.
+//
+// A "block" is the A-operand data of one (layer, 32-row output tile): for each 16-deep k-step two 1 KiB
+// fragments (hi, lo) in lane order (lane l = 16 bytes at offset 16*l), so that one ds_read_b128 per lane
+// fetches an MFMA A operand and a block can be copied global -> LDS linearly.
+//
+//   k order inside a k-step (lane half h = lane>>5, element e = 0..7), hidden layers:
+//       input feature = 32*(s>>1) + 16*(s&1) + 8*(e>>2) + 4*h + (e&3)
+//     i.e. exactly the feature that accumulator register 8*(s&1)+e of tile s>>1 holds on lane half h.
+//   in_layer (positional encoding, 84 inputs padded to 96 = 6 k-steps), slot q = 8*s + e:
+//       q < 40      : lane half 0 -> sin feature (reference column 4 + q), half 1 -> cos (column 44 + q)
+//       40 <= q < 44: lane half 0 -> raw coordinate q-40 (reference column q-40), half 1 -> zero
+//       q >= 44     : zero
+//
+// Byte layout of the packed image for (D = d_filter, n_linear Linear layers):
+//   [in_layer : D/32 blocks of 6*2048 B][hidden l=1..n_linear-2 : D/32 blocks of (D/16)*2048 B each]
+//   [out_layer: 1 block of (D/16)*2048 B, rows >= d_out zero][bias fp32: (n_linear-1)*D, then 32 (out layer)]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define SUNERF_KS0 6  // k-steps of the in layer (96 = 84 padded)
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct PackedLayout {
+  int D, n_linear, NT, KS;
+  size_t blk0, blk;
+  __host__ __device__ PackedLayout(int d, int nl) : D(d), n_linear(nl), NT(d / 32), KS(d / 16),
+                                                     blk0((size_t)SUNERF_KS0 * 2048), blk((size_t)(d / 16) * 2048) {}
+  __host__ __device__ size_t block_off(int l, int U) const {
+    if (l == 0) return (size_t)U * blk0;
+    size_t base = (size_t)NT * blk0;
+    if (l < n_linear - 1) return base + ((size_t)(l - 1) * NT + U) * blk;
+    return base + (size_t)(n_linear - 2) * NT * blk;
+  }
+  __host__ __device__ size_t bias_off() const { return (size_t)NT * blk0 + (size_t)(n_linear - 2) * NT * blk + blk; }
+  __host__ __device__ size_t n_bias() const { return (size_t)(n_linear - 1) * D + 32; }
+  __host__ __device__ size_t total_bytes() const { return bias_off() + n_bias() * 4; }
+};
+
+// input feature (column of the nn.Linear weight) held by (k-step s, lane half h, element e); -1 = zero pad
+__host__ __device__ inline int kmap_hidden(int s, int h, int e) {
+  return 32 * (s >> 1) + 16 * (s & 1) + 8 * (e >> 2) + 4 * h + (e & 3);
+}
+__host__ __device__ inline int kmap_encoding(int s, int h, int e) {
+  int q = 8 * s + e;
+  if (q < 40) return 4 + 40 * h + q;
+  if (q < 44 && h == 0) return q - 40;
+  return -1;
+}
+// row of a 32x32 accumulator tile held by register g on lane half h
+__host__ __device__ inline int acc_row(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
+
+#define SUNERF_CHECK_LAUNCH()                         \
+  do {                                                \
+    hipError_t e__ = hipGetLastError();               \
+    if (e__ != hipSuccess) return (int)e__;           \
+  } while (0)

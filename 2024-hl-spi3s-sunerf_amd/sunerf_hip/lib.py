@@ -1,0 +1,68 @@
+"""ctypes binding of libsunerf_hip.so (C ABI: include/sunerf_hip.h).
+
+The library is built in-tree by ``csrc/build.sh`` (``__graft_entry__.build()``).  There is no CPU fallback: if
+the library is missing or a tensor is not on a ROCm device the call raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libsunerf_hip.so')
+
+_lib = None
+
+c_f32p = ctypes.c_void_p   # device pointers travel as raw addresses
+c_void = ctypes.c_void_p
+
+_SIGNATURES = {
+    'sunerf_abi_version': (ctypes.c_int, []),
+    'sunerf_packed_mlp_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    'sunerf_pack_mlp': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, c_void, c_void]),
+    'sunerf_sample_z': (ctypes.c_int, [ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int64, ctypes.c_int,
+                                        ctypes.c_float, ctypes.c_float, c_f32p, c_void]),
+    'sunerf_act_stash_bytes': (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    'sunerf_emission_render_fwd': (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p,
+                                                   ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p,
+                                                   c_f32p, c_f32p, c_f32p, ctypes.c_float, c_void, c_void]),
+    'sunerf_hier_resample': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                             ctypes.c_int, c_f32p, c_f32p, c_void]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class SunerfHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the library once; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SunerfHipError(
+                f'{LIB_PATH} not found: build it with 2024-hl-spi3s-sunerf_amd/csrc/build.sh '
+                '(or __graft_entry__.build()); there is no CPU fallback for the render path')
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.sunerf_abi_version() != 1:
+            raise SunerfHipError('libsunerf_hip.so ABI version mismatch')
+        _lib = lib
+    return _lib
+
+
+_ERRORS = {-1: 'bad argument (null pointer or non-positive size)',
+           -2: 'unsupported configuration (d_filter / n_layers / sample count outside the compiled set)',
+           -3: 'workspace too small'}
+
+
+def check(status, what):
+    if status == 0:
+        return
+    if status in (-1, -2, -3):
+        raise ValueError(f'{what}: {_ERRORS[status]}')
+    raise SunerfHipError(f'{what}: HIP error {status}')

@@ -1,0 +1,139 @@
+"""Tensor-level wrappers over the C ABI: argument validation, output allocation, current-stream plumbing.
+
+PyTorch is used for device memory and streams only; every numerical op of the render path runs in the HIP
+kernels of ``csrc/``.
+"""
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as _l
+
+SAMPLER_STRATIFIED = 0
+SAMPLER_SPHERICAL = 1
+SUPPORTED_D_FILTER = (64, 128, 256)
+
+
+def _dev(t: torch.Tensor, name: str, shape=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f'{name} must be a torch.Tensor')
+    if not t.is_cuda:
+        raise _l.SunerfHipError(f'{name} is on {t.device}: the fused renderer has no CPU path '
+                                '(move the module and its inputs to a ROCm device)')
+    if t.dtype != torch.float32:
+        raise TypeError(f'{name} must be float32, got {t.dtype}')
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f'{name} has shape {tuple(t.shape)}, expected {tuple(shape)}')
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class PackedMLP:
+    """fp16 hi/lo A-fragment image of one NeRF MLP (see csrc/sunerf_common.h).  Re-pack after every
+    parameter update (``repack``)."""
+
+    def __init__(self, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]):
+        self.n_linear = len(weights)
+        self.d_filter = int(weights[0].shape[0])
+        self.d_out = int(weights[-1].shape[0])
+        if self.d_filter not in SUPPORTED_D_FILTER:
+            raise ValueError(f'd_filter={self.d_filter} is not in the compiled set {SUPPORTED_D_FILTER}')
+        if int(weights[0].shape[1]) != 84:
+            raise ValueError("only encoding='positional' (84 input features) is supported by the fused kernel")
+        lib = _l.load()
+        nbytes = lib.sunerf_packed_mlp_bytes(self.d_filter, self.n_linear)
+        if nbytes == 0:
+            raise ValueError(f'unsupported MLP shape: d_filter={self.d_filter}, n_linear={self.n_linear}')
+        self.device = weights[0].device
+        self.buffer = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.repack(weights, biases)
+
+    def repack(self, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]):
+        lib = _l.load()
+        assert len(weights) == self.n_linear and len(biases) == self.n_linear
+        ws, bs = [], []
+        for i, (w, b) in enumerate(zip(weights, biases)):
+            d_in = 84 if i == 0 else self.d_filter
+            d_o = self.d_out if i == self.n_linear - 1 else self.d_filter
+            ws.append(_dev(w.detach(), f'weight[{i}]', (d_o, d_in)))
+            bs.append(_dev(b.detach(), f'bias[{i}]', (d_o,)))
+        W = (ctypes.c_void_p * self.n_linear)(*[w.data_ptr() for w in ws])
+        B = (ctypes.c_void_p * self.n_linear)(*[b.data_ptr() for b in bs])
+        st = lib.sunerf_pack_mlp(W, B, self.n_linear, self.d_filter, self.d_out, _ptr(self.buffer),
+                                 _stream(self.device))
+        _l.check(st, 'sunerf_pack_mlp')
+        self._keepalive = (ws, bs)   # until the pack kernel has run on the stream
+
+
+def sample_z(kind: int, rays_o, rays_d, t_vals, distance: float, solar_R: float,
+             t_rand: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _l.load()
+    n = rays_o.shape[0]
+    rays_o = _dev(rays_o, 'rays_o', (n, 3))
+    rays_d = _dev(rays_d, 'rays_d', (n, 3))
+    t_vals = _dev(t_vals.reshape(-1), 't_vals')
+    s = t_vals.numel()
+    if t_rand is not None:
+        t_rand = _dev(t_rand, 't_rand', (n, s))
+    z = torch.empty(n, s, dtype=torch.float32, device=rays_o.device)
+    st = lib.sunerf_sample_z(kind, _ptr(rays_o), _ptr(rays_d), _ptr(t_vals), _ptr(t_rand), n, s,
+                             float(distance), float(solar_R), _ptr(z), _stream(rays_o.device))
+    _l.check(st, 'sunerf_sample_z')
+    return z
+
+
+def emission_render_fwd(packed: PackedMLP, rays_o, rays_d, times, z_vals, reg_radius: float,
+                        want_raw: bool = False, want_epilogues: bool = False):
+    """One fused render pass.  Returns dict(image (N,1), weights (N,S), absorption (N,S)[, raw (N,S,2)]
+    [, height_map (N,), absorption_map (N,), regularization (N,S)])."""
+    lib = _l.load()
+    n, s = z_vals.shape
+    dev = z_vals.device
+    rays_o = _dev(rays_o, 'rays_o', (n, 3))
+    rays_d = _dev(rays_d, 'rays_d', (n, 3))
+    times = _dev(times.reshape(-1), 'times', (n,))
+    z_vals = _dev(z_vals, 'z_vals', (n, s))
+    if packed.device != dev:
+        raise _l.SunerfHipError('packed weights and rays are on different devices')
+    f32 = dict(dtype=torch.float32, device=dev)
+    out = {'image': torch.empty(n, 1, **f32), 'weights': torch.empty(n, s, **f32),
+           'absorption': torch.empty(n, s, **f32)}
+    raw = torch.empty(n, s, 2, **f32) if want_raw else None
+    hm = am = reg = None
+    if want_epilogues:
+        hm, am, reg = torch.empty(n, **f32), torch.empty(n, **f32), torch.empty(n, s, **f32)
+    st = lib.sunerf_emission_render_fwd(_ptr(packed.buffer), packed.d_filter, packed.n_linear, _ptr(rays_o),
+                                        _ptr(rays_d), _ptr(times), _ptr(z_vals), n, s, _ptr(out['image']),
+                                        _ptr(out['weights']), _ptr(out['absorption']), _ptr(raw), _ptr(hm), _ptr(am),
+                                        _ptr(reg), float(reg_radius), None, _stream(dev))
+    _l.check(st, 'sunerf_emission_render_fwd')
+    if want_raw:
+        out['raw'] = raw
+    if want_epilogues:
+        out.update(height_map=hm, absorption_map=am, regularization=reg)
+    return out
+
+
+def hier_resample(z_vals, weights, u: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``u``: (S_f,) shared sample positions (perturb=False) or (N, S_f) per-ray (perturb=True)."""
+    lib = _l.load()
+    n, sc = z_vals.shape
+    z_vals = _dev(z_vals, 'z_vals', (n, sc))
+    weights = _dev(weights.detach(), 'weights', (n, sc))
+    per_ray = int(u.dim() == 2)
+    sf = u.shape[-1]
+    u = _dev(u, 'u', (n, sf) if per_ray else (sf,))
+    new_z = torch.empty(n, sf, dtype=torch.float32, device=z_vals.device)
+    z_comb = torch.empty(n, sc + sf, dtype=torch.float32, device=z_vals.device)
+    st = lib.sunerf_hier_resample(_ptr(z_vals), _ptr(weights), _ptr(u), per_ray, n, sc, sf, _ptr(new_z),
+                                  _ptr(z_comb), _stream(z_vals.device))
+    _l.check(st, 'sunerf_hier_resample')
+    return new_z, z_comb

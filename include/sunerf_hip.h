@@ -1,0 +1,115 @@
+/*
+ * sunerf_hip.h -- C ABI of the MI355X (gfx950) SuNeRF ray-march renderer.
+ *
+ * The reference (FrontierDevelopmentLab/2024-HL-SPI3S-SuNeRF) has no FFI / plugin registry: its hot path is
+ * the Python class API of sunerf.rendering + sunerf.model + sunerf.train.sampling.  This
+ * header is the drop-in boundary *under* that API: every entry point replaces a span of aten ops of one
+ * reference function (cited per function, paths relative to the reference root) and is called by the Python
+ * mirror classes in 2024-hl-spi3s-sunerf_amd/sunerf/ through ctypes.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HIP, same device as `stream`) unless the name ends in `_host`;
+ *   - fp32 row-major contiguous tensors, shapes given per argument;
+ *   - no allocation, no host synchronisation, no ownership transfer: callers own inputs, outputs and
+ *     workspaces; every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - returns 0 on success, a negative SUNERF_E_* code on argument errors, a positive hipError_t if a launch
+ *     failed.  The Python side turns non-zero into RuntimeError / ValueError.
+ *   - thread-safe / re-entrant: no global mutable state (evaluation/loader.py:226-229 calls the renderer from
+ *     a ThreadPoolExecutor).
+ */
+#ifndef SUNERF_HIP_H
+#define SUNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SUNERF_ABI_VERSION 1
+
+#define SUNERF_E_BADARG   (-1)   /* null pointer / non-positive size                               */
+#define SUNERF_E_UNSUPPORTED (-2) /* d_filter / n_layers / sample count outside the compiled set     */
+#define SUNERF_E_WORKSPACE (-3)  /* workspace too small                                             */
+
+#define SUNERF_MAX_LAYERS 16     /* Linear layers per MLP including in_layer and out_layer          */
+#define SUNERF_ENC_DIM    84     /* PositionalEncoding(d_input=4, n_freqs=10).d_output, model.py:109 */
+
+/* sampler kinds -- sunerf/train/sampling.py */
+#define SUNERF_SAMPLER_STRATIFIED 0   /* StratifiedSampler.forward  sampling.py:68-102 */
+#define SUNERF_SAMPLER_SPHERICAL  1   /* SphericalSampler.forward   sampling.py:16-54  */
+
+int sunerf_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Weight packing.  The fused renderer consumes the MLP weights as fp16 hi/lo pairs (w = hi + lo, |err| <= 2^-22
+ * relative) stored in MFMA A-fragment order, plus fp32 biases.  Must be re-run after every optimiser step.
+ *
+ * Replaces: nothing numerically -- it is a re-layout of the nn.Linear parameters of NeRF (model.py:28-42).
+ *
+ *   weights_host[i] -> device fp32 W_i [out_i, in_i] row-major (nn.Linear layout), i = 0..n_linear-1
+ *   biases_host[i]  -> device fp32 b_i [out_i]
+ *   n_linear = n_layers + 1 : in_layer (84 -> d_filter), n_layers-1 hidden (d_filter -> d_filter), out_layer
+ *   packed: device buffer of sunerf_packed_mlp_bytes() bytes, 16-byte aligned
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t sunerf_packed_mlp_bytes(int d_filter, int n_linear);
+
+int sunerf_pack_mlp(const float* const* weights_host, const float* const* biases_host, int n_linear,
+                    int d_filter, int d_out, void* packed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Sample placement along rays.
+ * Replaces StratifiedSampler.forward sampling.py:68-98 / SphericalSampler.forward sampling.py:16-49 (z_vals only;
+ * the points o + d*z of :100 / :52 are formed inside the render kernel and never materialised).
+ *
+ *   rays_o, rays_d [N,3]; t_vals [S] (the module buffer, sampling.py:65-66); t_rand [N,S] or NULL
+ *   (perturb=False); distance = sampler.distance buffer, solar_R = sampler.solar_R buffer; z_vals out [N,S]
+ * ---------------------------------------------------------------------------------------------------------- */
+int sunerf_sample_z(int sampler_kind, const float* rays_o, const float* rays_d, const float* t_vals,
+                    const float* t_rand, int64_t n_rays, int n_samples, float distance, float solar_R,
+                    float* z_vals, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused render pass: points -> time concat -> positional encoding -> MLP -> emission/absorption integral.
+ * Replaces, for one coarse or fine pass:
+ *   sampling.py:100 (points), base_tracing.py:64-65 / :83-84 (time concat), base_tracing.py:118-129 (_render),
+ *   model.py:123-132 (PositionalEncoding.forward), model.py:44-57 (NeRF.forward), emission.py:14-54
+ *   (raw2outputs), base_tracing.py:135-156 (cumprod_exclusive), and the epilogues base_tracing.py:99-110
+ *   (absorption_map, distance, height_map, regularization with defect D2 resolved to (N,S)).
+ *
+ *   packed     : sunerf_pack_mlp output for this pass's model
+ *   rays_o/d   : [N,3]; times [N] (the (N,1) column); z_vals [N,S]
+ *   image      : [N]    sum_S I*T                                  (emission.py:46)
+ *   weights    : [N,S]  I*T / (sum + 1e-10)                        (emission.py:49-50)
+ *   absorption : [N,S]  exp(-relu(r1)*dists)  'regularizing_quantity' (emission.py:35)
+ *   raw        : [N,S,2] MLP output ('inferences'), may be NULL
+ *   height_map, absorption_map : [N] or NULL;  regularization : [N,S] or NULL  (base_tracing.py:99-106)
+ *   reg_radius : 1.2 / Rs_per_ds (base_tracing.py:44)
+ *   act_stash  : NULL for inference; for training a device buffer of sunerf_act_stash_bytes() bytes that
+ *                receives the hidden activations for sunerf_emission_render_bwd
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t sunerf_act_stash_bytes(int64_t n_rays, int n_samples, int d_filter, int n_linear);
+
+int sunerf_emission_render_fwd(const void* packed, int d_filter, int n_linear,
+                               const float* rays_o, const float* rays_d, const float* times,
+                               const float* z_vals, int64_t n_rays, int n_samples,
+                               float* image, float* weights, float* absorption, float* raw,
+                               float* height_map, float* absorption_map, float* regularization,
+                               float reg_radius, void* act_stash, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Hierarchical (inverse-CDF) resampling + merge.
+ * Replaces HierarchicalSampler.forward / sample_pdf, sampling.py:111-169 (perturb=False: u = linspace(0,1,S_f),
+ * passed in as the tensor `u` [S_f] so that torch.linspace's own fp32 values are used; or a per-ray u [N,S_f]
+ * with u_per_ray != 0 for perturb=True).
+ *
+ *   z_vals [N,S_c], weights [N,S_c] -> new_z [N,S_f], z_comb [N,S_c+S_f] (sorted)
+ * ---------------------------------------------------------------------------------------------------------- */
+int sunerf_hier_resample(const float* z_vals, const float* weights, const float* u, int u_per_ray,
+                         int64_t n_rays, int n_coarse, int n_fine, float* new_z, float* z_comb, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUNERF_HIP_H */
