@@ -1,0 +1,84 @@
+"""Mirror of the reference's ``sunerf/model/model.py``: parameter containers with the reference's module tree
+(state-dict keys ``in_layer.0.freq_bands``, ``in_layer.1.{weight,bias}``, ``layers.{i}.{weight,bias}``,
+``out_layer.{weight,bias}``) and default ``nn.Linear`` initialisation.  The arithmetic is done by the fused HIP
+kernels on a packed fp16 hi/lo image of these parameters (``sunerf_hip.ops.PackedMLP``)."""
+from typing import Tuple
+
+import torch
+from torch import nn
+
+from sunerf_hip import ops
+
+
+class Sine(nn.Module):
+    """model.py:66-72.  The fused kernels implement w0 = 1 (the only value the reference ever constructs)."""
+
+    def __init__(self, w0: float = 1.):
+        super().__init__()
+        self.w0 = w0
+
+
+class PositionalEncoding(nn.Module):
+    """model.py:92-132: [x, sin(x f_k / 2), cos(x f_k / 2)], f_k = 2^k, k = 0..n_freqs-1 (fused into the kernel)."""
+
+    def __init__(self, d_input: int, n_freqs: int, scale_factor: float = 2., log_space: bool = True):
+        super().__init__()
+        if d_input != 4 or n_freqs != 10 or scale_factor != 2. or not log_space:
+            raise ValueError('the fused kernel implements PositionalEncoding(d_input=4, n_freqs=10, scale_factor=2, '
+                             'log_space=True), the only configuration NeRF constructs (model.py:29)')
+        self.d_input = d_input
+        self.n_freqs = n_freqs
+        self.log_space = log_space
+        self.d_output = d_input * (1 + 2 * n_freqs)
+        self.register_buffer('freq_bands', 2. ** torch.linspace(0., n_freqs - 1, n_freqs))
+        self.scale_factor = scale_factor
+
+
+class NeRF(nn.Module):
+    """model.py:7-57."""
+
+    def __init__(self, d_input: int = 4, d_output: int = 2, n_layers: int = 8, d_filter: int = 512,
+                 skip: Tuple[int] = (), encoding='positional'):
+        super().__init__()
+        if encoding != 'positional':
+            raise ValueError("only encoding='positional' is implemented by the fused kernel")
+        if d_filter not in ops.SUPPORTED_D_FILTER:
+            raise ValueError(f'd_filter={d_filter} is not in the compiled set {ops.SUPPORTED_D_FILTER}')
+        self.d_input = d_input
+        self.skip = skip
+        self.act = Sine()
+        enc = PositionalEncoding(d_input=d_input, n_freqs=10)
+        self.in_layer = nn.Sequential(enc, nn.Linear(enc.d_output, d_filter))
+        self.layers = nn.ModuleList([nn.Linear(d_filter, d_filter) for _ in range(n_layers - 1)])
+        self.out_layer = nn.Linear(d_filter, d_output)
+        self._packed = None
+        self._packed_key = None
+
+    # -- parameter views in evaluation order -----------------------------------------------------------------
+    def linears(self):
+        return [self.in_layer[1]] + list(self.layers) + [self.out_layer]
+
+    def packed(self) -> 'ops.PackedMLP':
+        """Packed image of the current parameters; re-packed when any parameter was modified in place
+        (optimizer step, load_state_dict) or moved."""
+        lin = self.linears()
+        key = tuple((p.data_ptr(), p._version) for l in lin for p in (l.weight, l.bias))
+        if self._packed is None or key != self._packed_key:
+            ws, bs = [l.weight for l in lin], [l.bias for l in lin]
+            if self._packed is None or self._packed.device != ws[0].device:
+                self._packed = ops.PackedMLP(ws, bs)
+            else:
+                self._packed.repack(ws, bs)
+            self._packed_key = key
+        return self._packed
+
+    def __getstate__(self):  # the packed image is a cache, not state (save_state pickles the module, sunerf.py:62-74)
+        st = self.__dict__.copy()
+        st['_packed'] = None
+        st['_packed_key'] = None
+        return st
+
+    def forward(self, x: torch.Tensor):
+        """(M, 4) query points -> {'inferences': (M, d_output)} (model.py:44-57)."""
+        from sunerf.rendering.functional import mlp_points
+        return {'inferences': mlp_points(self, x)}

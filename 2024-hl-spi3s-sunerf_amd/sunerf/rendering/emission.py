@@ -1,0 +1,31 @@
+"""Mirror of the reference's ``sunerf/rendering/emission.py`` on the fused HIP path."""
+import torch
+
+from sunerf.rendering.base_tracing import SuNeRFRendering
+from sunerf_hip import ops
+
+
+class EmissionRadiativeTransfer(SuNeRFRendering):
+
+    def __init__(self, model_config=None, **kwargs):
+        model_config = {} if model_config is None else model_config
+        model_config.update({'d_input': 4, 'd_output': 2, })  # emission.py:11
+        super().__init__(model_config=model_config, **kwargs)
+
+    def forward(self, rays_o, rays_d, times, wavelengths=None):
+        """base_tracing.py:46-111 for the emission subclass: same 8 output keys."""
+        if wavelengths is not None:
+            raise ValueError('EmissionRadiativeTransfer takes no wavelengths')
+        z_vals = self.sampler.z_vals(rays_o, rays_d)
+        reg_radius = 1.2 / self.Rs_per_ds
+        coarse = ops.emission_render_fwd(self.coarse_model.packed(), rays_o, rays_d, times, z_vals, reg_radius)
+        new_z, z_comb = self.sampler_hierarchical.resample(z_vals, coarse['weights'])
+        fine = ops.emission_render_fwd(self.fine_model.packed(), rays_o, rays_d, times, z_comb, reg_radius,
+                                       want_epilogues=True)
+        return {'z_vals_stratified': z_vals, 'coarse_image': coarse['image'], 'z_vals_hierarchical': new_z,
+                'fine_image': fine['image'], 'image': fine['image'], 'height_map': fine['height_map'],
+                'absorption_map': fine['absorption_map'], 'regularization': fine['regularization']}
+
+    def raw2outputs(self, raw: torch.Tensor, z_vals: torch.Tensor, rays_d: torch.Tensor, **kwargs):
+        raise NotImplementedError('raw2outputs is fused into the render kernel (sunerf_emission_render_fwd); '
+                                  'call forward()')

@@ -1,0 +1,81 @@
+"""End-to-end parity of the drop-in module API against the REFERENCE's own outputs (golden g5/g5b), on MI355X.
+
+North-star tolerance: image-like outputs within 1e-4 rel (fp32) of the reference CPU renderer.  The fine pass sits
+behind the inverse-CDF resampling, which amplifies coarse-weight noise, so:
+  * z_vals_stratified: bit-exact;  coarse_image: 1e-4 rel
+  * z_vals_hierarchical: 2e-4 absolute on z ~ 215 (13 ulp)
+  * fine outputs: 1e-4 rel when the fine pass is fed the reference's own z_vals_combined (stage-wise), and
+    2e-4 rel end-to-end
+"""
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _module(g, d_filter, n_c, n_f):
+    from sunerf.rendering.emission import EmissionRadiativeTransfer
+    mod = EmissionRadiativeTransfer(Rs_per_ds=1.0,
+                                    sampling_config={'type': 'stratified', 'n_samples': n_c, 'perturb': False},
+                                    hierarchical_sampling_config={'type': 'hierarchical', 'n_samples': n_f},
+                                    model_config={'d_filter': d_filter})
+    sd = {k[4:].replace('__', '.'): v for k, v in g.items() if k.startswith('sd__')}
+    missing, unexpected = mod.load_state_dict(sd, strict=True), None
+    return mod.cuda()
+
+
+def rel(a, b):
+    err = (a.detach().cpu() - b).abs().max().item()
+    return err / max(b.abs().max().item(), 1e-6)     # all-zero reference (e.g. no absorption anywhere): absolute
+
+
+@pytest.mark.parametrize('name,d_filter,n_c,n_f', [('g5_emission_e2e', 64, 32, 32), ('g5b_emission_d256', 256, 32, 64)])
+def test_forward_matches_reference(name, d_filter, n_c, n_f):
+    g = load_golden(name)
+    mod = _module(g, d_filter, n_c, n_f)
+    out = mod(g['rays_o'].cuda(), g['rays_d'].cuda(), g['times'].cuda())
+    assert set(out) == {'z_vals_stratified', 'coarse_image', 'z_vals_hierarchical', 'fine_image', 'image',
+                        'height_map', 'absorption_map', 'regularization'}
+    for k, v in out.items():
+        assert v.shape == g['out__' + k].shape, k
+        assert torch.isfinite(v).all(), k
+    assert torch.equal(out['z_vals_stratified'].cpu(), g['out__z_vals_stratified'])
+    assert rel(out['coarse_image'], g['out__coarse_image']) < 1e-4
+    assert (out['z_vals_hierarchical'].cpu() - g['out__z_vals_hierarchical']).abs().max().item() < 2e-4
+    for k in ('fine_image', 'image', 'height_map', 'absorption_map'):
+        assert rel(out[k], g['out__' + k]) < 2e-4, k
+    assert (out['regularization'].cpu() - g['out__regularization']).abs().max().item() \
+        < 2e-4 * g['out__regularization'].abs().max().item() + 1e-7
+
+
+def test_state_dict_keys_match_reference():
+    g = load_golden('g5_emission_e2e')
+    mod = _module(g, 64, 32, 32)
+    want = {k[4:].replace('__', '.') for k in g if k.startswith('sd__')}
+    assert set(mod.state_dict().keys()) == want
+
+
+def test_forward_points_and_model_call():
+    g = load_golden('g2_mlp')
+    from sunerf.model.model import NeRF
+    net = NeRF(d_input=4, d_output=2, n_layers=8, d_filter=64)
+    net.load_state_dict({k[5:].replace('__', '.'): v for k, v in g.items() if k.startswith('net__')})
+    net = net.cuda()
+    out = net(g['x'].cuda())
+    assert set(out) == {'inferences'}
+    assert (out['inferences'].cpu() - g['inferences']).abs().max().item() < 2e-5
+
+
+def test_repack_after_inplace_update():
+    g = load_golden('g5_emission_e2e')
+    mod = _module(g, 64, 32, 32)
+    o, d, t = g['rays_o'].cuda(), g['rays_d'].cuda(), g['times'].cuda()
+    a = mod(o, d, t)['coarse_image'].clone()
+    with torch.no_grad():
+        mod.coarse_model.out_layer.bias[0].add_(0.5)   # in-place, like an optimizer step
+    b = mod(o, d, t)['coarse_image']
+    # exp(r0 + 0.5): the image scales by e^0.5 exactly when only the emission bias moves
+    want = (a * torch.exp(torch.tensor(0.5))).cpu()
+    assert rel(b, want) < 1e-5
