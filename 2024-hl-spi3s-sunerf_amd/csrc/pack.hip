@@ -83,6 +83,7 @@ extern "C" int sunerf_pack_mlp(const float* const* weights_host, const float* co
                        (size_t)L.KS * 512 + L.n_bias();
   const int threads = 256;
   const unsigned blocks = (unsigned)((total + threads - 1) / threads);
+  SUNERF_CLEAR_ERROR();
   hipLaunchKernelGGL(pack_mlp_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, a);
   SUNERF_CHECK_LAUNCH();
   return 0;

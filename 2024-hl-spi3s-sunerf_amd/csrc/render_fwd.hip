@@ -298,6 +298,7 @@ int launch_render(const RenderArgs& a, hipStream_t stream) {
   hipGetDevice(&dev);
   hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const unsigned grid = (unsigned)(n_groups < cus ? n_groups : cus);
+  SUNERF_CLEAR_ERROR();
   hipLaunchKernelGGL(render_fwd_kernel<D>, dim3(grid), dim3(THREADS), lds, stream, a);
   SUNERF_CHECK_LAUNCH();
   return 0;

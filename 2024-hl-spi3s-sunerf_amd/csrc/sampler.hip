@@ -144,6 +144,7 @@ extern "C" int sunerf_sample_z(int sampler_kind, const float* rays_o, const floa
   const int threads = 256;
   const int64_t blocks = (total + threads - 1) / threads;
   if (blocks > 0x7fffffffLL) return SUNERF_E_UNSUPPORTED;
+  SUNERF_CLEAR_ERROR();
   hipLaunchKernelGGL(sample_z_kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, sampler_kind,
                      rays_o, rays_d, t_vals, t_rand, n_rays, n_samples, distance, solar_R, z_vals);
   SUNERF_CHECK_LAUNCH();
@@ -164,6 +165,7 @@ extern "C" int sunerf_hier_resample(const float* z_vals, const float* weights, c
     hipError_t e = hipFuncSetAttribute((const void*)hier_resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
+  SUNERF_CLEAR_ERROR();
   hipLaunchKernelGGL(hier_resample_kernel, dim3((unsigned)blocks), dim3(RS_THREADS), lds, (hipStream_t)stream, z_vals,
                      weights, u, u_per_ray, n_rays, n_coarse, n_fine, new_z, z_comb);
   SUNERF_CHECK_LAUNCH();

@@ -69,6 +69,9 @@ __host__ __device__ inline int kmap_encoding(int s, int h, int e) {
 // row of a 32x32 accumulator tile held by register g on lane half h
 __host__ __device__ inline int acc_row(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 
+// hipGetLastError() reports the last error of ANY earlier runtime call on this thread (e.g. a probe made by the
+// caller's framework): clear it before a launch so that the check after the launch sees only our own.
+#define SUNERF_CLEAR_ERROR() (void)hipGetLastError()
 #define SUNERF_CHECK_LAUNCH()                         \
   do {                                                \
     hipError_t e__ = hipGetLastError();               \

@@ -6,6 +6,12 @@ the library is missing or a tensor is not on a ROCm device the call raises.
 import ctypes
 import os
 
+# PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  It must be mapped
+# BEFORE libsunerf_hip.so so that our library binds to the same runtime instance (streams and device pointers are
+# shared with torch); loading ours first would pull in /opt/rocm's copy and every launch fails with
+# hipErrorNoDevice (100).
+import torch  # noqa: F401  (side effect: loads torch's HIP runtime)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libsunerf_hip.so')
 
