@@ -94,10 +94,63 @@ __device__ __forceinline__ float shfl_up32(float v, int d, int n) {  // within t
   return o;
 }
 
-// stage one weight block global -> LDS (v1: through registers, synchronous)
-__device__ __forceinline__ void stage_block(char* dst, const char* src, int bytes, int tid) {
-  for (int off = tid * 16; off < bytes; off += THREADS * 16) *(f32x4*)(dst + off) = *(const f32x4*)(src + off);
-}
+// ---- weight stream: global (L2-resident packed image) -> LDS ring, asynchronous LDS-DMA ------------------------
+// The (layer, tile) blocks are consumed in a fixed cyclic order (all blocks of the MLP once per 32-sample chunk),
+// so the stream is a ring of NSLOT slots filled two blocks ahead by `global_load_lds_dwordx4` (no VGPR staging):
+// each of the 4 waves issues a quarter of a block's 1 KiB pieces.  Per block step:
+//     s_waitcnt vmcnt(#pieces of the NEXT block)   -> this wave's pieces of the CURRENT block have landed
+//     s_barrier                                    -> everyone's pieces landed; everyone is done reading the
+//                                                     previous block, whose slot is the one refilled next
+//     issue the DMA of block (current + 2)
+//     compute on the current slot
+// The DMA is inline asm on purpose: hipcc does not count it, so it neither drains it with vmcnt(0) at barriers nor
+// in front of unrelated LDS reads; our counted waits stay valid when compiler-issued loads/stores interleave
+// (extra younger operations only make `vmcnt(N)` stricter).
+template <int D>
+struct Ring {
+  static constexpr int BLK0 = SUNERF_KS0 * 2048;
+  static constexpr int BLK = (D / 16) * 2048;
+  static constexpr int SLOT = BLK > BLK0 ? BLK : BLK0;   // ring slot size
+  static constexpr int CNT0 = BLK0 / 1024 / WAVES;   // DMA pieces per wave, in-layer block
+  static constexpr int CNT = BLK / 1024 / WAVES;     // hidden / out block
+  static_assert(BLK0 % (1024 * WAVES) == 0 && BLK % (1024 * WAVES) == 0, "blocks must split evenly over the waves");
+  const char* packed;
+  unsigned lds_base;   // LDS byte address of slot 0
+  int nb, nt;          // blocks per MLP pass, of which the first nt are in-layer blocks
+  int cur, pf;         // next block to consume / to prefetch (0..nb-1)
+  int cslot, pslot;    // their ring slots
+  int wave, lane;
+
+  __device__ __forceinline__ void issue() {
+    const bool small = pf < nt;
+    const size_t off = small ? (size_t)pf * BLK0 : (size_t)nt * BLK0 + (size_t)(pf - nt) * BLK;
+    const int cnt = small ? CNT0 : CNT;
+    const char* src = packed + off + (size_t)(wave * cnt) * 1024 + lane * 16;
+    unsigned dst = lds_base + pslot * SLOT + wave * cnt * 1024;
+    for (int i = 0; i < cnt; ++i) {
+      unsigned keep;
+      const unsigned dst_u = __builtin_amdgcn_readfirstlane(dst);
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst_u) : "memory");
+      src += 1024; dst += 1024;
+    }
+    pf = (pf + 1 == nb) ? 0 : pf + 1;
+    pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
+  }
+  __device__ __forceinline__ void prologue() { issue(); issue(); }
+  // returns the LDS byte offset (from slot 0) of the block to consume
+  __device__ __forceinline__ int acquire() {
+    const int nxt = (cur + 1 == nb) ? 0 : cur + 1;
+    if (nxt < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(CNT0) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(CNT) : "memory");
+    __builtin_amdgcn_s_barrier();
+    issue();
+    const int off = cslot * SLOT;
+    cur = nxt;
+    cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
+    return off;
+  }
+};
 
 // one 32-row output tile: acc = bias + W_tile * X   (three fp16 MFMAs per k-step)
 template <int KSTEPS>
@@ -140,26 +193,21 @@ struct Mlp {
   static constexpr int BLK0 = SUNERF_KS0 * 2048;
   static constexpr int BLK = KS * 2048;
 
-  // hidden layer: X (KIN k-steps) -> Y (KS k-steps); blocks streamed through LDS
+  // one layer: X (KIN k-steps) -> Y (KS k-steps); weight blocks come through the LDS ring
   template <int KIN>
-  static __device__ __forceinline__ void layer(const char* gblocks, int blk_bytes, char* slot, const float* bias,
-                                               int tid, int lane, int h, const half8* xhi, const half8* xlo,
-                                               half8* yhi, half8* ylo) {
+  static __device__ __forceinline__ void layer(Ring<D>& ring, const char* slots, const float* bias, int lane, int h,
+                                               const half8* xhi, const half8* xlo, half8* yhi, half8* ylo) {
 #pragma unroll
     for (int U = 0; U < NT; ++U) {
-      __syncthreads();
-      stage_block(slot, gblocks + (size_t)U * blk_bytes, blk_bytes, tid);
-      __syncthreads();
+      const char* slot = slots + ring.acquire();
       const f32x16 acc = tile_mma<KIN>(slot, bias + 32 * U, lane, h, xhi, xlo);
       activate_tile(acc, yhi[2 * U], ylo[2 * U], yhi[2 * U + 1], ylo[2 * U + 1]);
     }
   }
 
-  static __device__ __forceinline__ f32x16 out_layer(const char* gblock, char* slot, const float* bias, int tid,
-                                                     int lane, int h, const half8* xhi, const half8* xlo) {
-    __syncthreads();
-    stage_block(slot, gblock, BLK, tid);
-    __syncthreads();
+  static __device__ __forceinline__ f32x16 out_layer(Ring<D>& ring, const char* slots, const float* bias, int lane,
+                                                     int h, const half8* xhi, const half8* xlo) {
+    const char* slot = slots + ring.acquire();
     return tile_mma<KS>(slot, bias, lane, h, xhi, xlo);
   }
 };
@@ -169,8 +217,8 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
   using M = Mlp<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const PackedLayout L(D, a.n_linear);
-  char* slot = smem;                                            // NSLOT * BLK (v1 uses slot 0 only)
-  float* bias = (float*)(smem + (size_t)NSLOT * M::BLK);         // n_bias floats
+  char* slot = smem;                                            // ring of NSLOT weight-block slots
+  float* bias = (float*)(smem + (size_t)NSLOT * Ring<D>::SLOT);  // n_bias floats
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, h = lane >> 5;
@@ -179,6 +227,15 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
     const float* gb = (const float*)(a.packed + L.bias_off());
     for (int i = tid; i < (int)L.n_bias(); i += THREADS) bias[i] = gb[i];
   }
+  __syncthreads();
+  Ring<D> ring;
+  ring.packed = a.packed;
+  ring.lds_base = (unsigned)(uintptr_t)slot;
+  ring.nt = M::NT;
+  ring.nb = M::NT * (a.n_linear - 1) + 1;
+  ring.cur = 0; ring.pf = 0; ring.cslot = 0; ring.pslot = 0;
+  ring.wave = __builtin_amdgcn_readfirstlane(wave); ring.lane = lane;
+  ring.prologue();
   const int S = a.S;
   const int n_chunks = (S + 31) >> 5;
   const int64_t n_groups = (a.n_rays + WAVES - 1) / WAVES;
@@ -214,20 +271,20 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
         });
       }
       // in layer: 84(96) -> D
-      M::template layer<SUNERF_KS0>(a.packed + L.block_off(0, 0), M::BLK0, slot, bias, tid, lane, h, xb_hi, xb_lo, xa_hi, xa_lo);
+      M::template layer<SUNERF_KS0>(ring, slot, bias, lane, h, xb_hi, xb_lo, xa_hi, xa_lo);
       // hidden layers, ping-pong between the two register sets
       int l = 1;
       for (; l + 1 < a.n_linear - 1; l += 2) {
-        M::template layer<M::KS>(a.packed + L.block_off(l, 0), M::BLK, slot, bias + (size_t)l * D, tid, lane, h, xa_hi, xa_lo, xb_hi, xb_lo);
-        M::template layer<M::KS>(a.packed + L.block_off(l + 1, 0), M::BLK, slot, bias + (size_t)(l + 1) * D, tid, lane, h, xb_hi, xb_lo, xa_hi, xa_lo);
+        M::template layer<M::KS>(ring, slot, bias + (size_t)l * D, lane, h, xa_hi, xa_lo, xb_hi, xb_lo);
+        M::template layer<M::KS>(ring, slot, bias + (size_t)(l + 1) * D, lane, h, xb_hi, xb_lo, xa_hi, xa_lo);
       }
       f32x16 out;
       const float* obias = bias + (size_t)(a.n_linear - 1) * D;
       if (l < a.n_linear - 1) {
-        M::template layer<M::KS>(a.packed + L.block_off(l, 0), M::BLK, slot, bias + (size_t)l * D, tid, lane, h, xa_hi, xa_lo, xb_hi, xb_lo);
-        out = M::out_layer(a.packed + L.block_off(a.n_linear - 1, 0), slot, obias, tid, lane, h, xb_hi, xb_lo);
+        M::template layer<M::KS>(ring, slot, bias + (size_t)l * D, lane, h, xa_hi, xa_lo, xb_hi, xb_lo);
+        out = M::out_layer(ring, slot, obias, lane, h, xb_hi, xb_lo);
       } else {
-        out = M::out_layer(a.packed + L.block_off(a.n_linear - 1, 0), slot, obias, tid, lane, h, xa_hi, xa_lo);
+        out = M::out_layer(ring, slot, obias, lane, h, xa_hi, xa_lo);
       }
 
       // ---- emission / absorption integral for this chunk (emission.py:14-54); lanes 0..31 hold rows 0,1 ----
@@ -284,12 +341,13 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two prefetches still in flight target our LDS: drain
 }
 
 template <int D>
 int launch_render(const RenderArgs& a, hipStream_t stream) {
   const PackedLayout L(D, a.n_linear);
-  const size_t lds = (size_t)NSLOT * Mlp<D>::BLK + L.n_bias() * 4;
+  const size_t lds = (size_t)NSLOT * Ring<D>::SLOT + L.n_bias() * 4;
   if (lds > 160 * 1024) return SUNERF_E_UNSUPPORTED;
   hipError_t e = hipFuncSetAttribute((const void*)render_fwd_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
