@@ -27,7 +27,7 @@ __global__ void pack_mlp_kernel(PackArgs a) {
     float* dst = (float*)(a.packed + L.bias_off());
     int l = (int)(i / a.D), f = (int)(i % a.D);
     float v;
-    if (l < a.n_linear - 1) v = a.b[l][f];
+    if (l < a.n_linear - 1) v = a.b[l][f] * 0.15915494309189535f;   // revolutions (see sunerf_common.h)
     else { int r = (int)(i - (size_t)(a.n_linear - 1) * a.D); v = r < a.d_out ? a.b[a.n_linear - 1][r] : 0.f; }
     dst[i] = v;
     return;
@@ -52,6 +52,7 @@ __global__ void pack_mlp_kernel(PackArgs a) {
   const int n_rows = (l == a.n_linear - 1) ? a.d_out : a.D;
   float w = 0.f;
   if (col >= 0 && row < n_rows) w = a.W[l][(size_t)row * in_dim + col];
+  if (l < a.n_linear - 1) w *= 0.15915494309189535f;   // pre-activation in revolutions for v_sin_f32
   const _Float16 hi = (_Float16)w;                  // round to nearest
   const _Float16 lo = (_Float16)(w - (float)hi);    // exact remainder, rounded to nearest (may be subnormal)
   _Float16* blk = (_Float16*)(a.packed + L.block_off(l, U));

@@ -14,12 +14,13 @@
 //   carry between chunks.
 #include "sunerf_common.h"
 #include "../../include/sunerf_hip.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int WAVES = 4;
 constexpr int THREADS = WAVES * 64;
-constexpr int NSLOT = 3;  // LDS ring slots for weight blocks
+constexpr int NSLOT = 4;  // LDS ring slots for weight blocks
 
 struct RenderArgs {
   const char* packed;
@@ -39,6 +40,7 @@ struct RenderArgs {
   float* regularization;
   float reg_radius;
   char* stash;
+  int debug;   // development ablations (SUNERF_DEBUG env): 1 = no weight DMA after the prologue (results invalid)
 };
 
 __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
@@ -95,120 +97,230 @@ __device__ __forceinline__ float shfl_up32(float v, int d, int n) {  // within t
 }
 
 // ---- weight stream: global (L2-resident packed image) -> LDS ring, asynchronous LDS-DMA ------------------------
-// The (layer, tile) blocks are consumed in a fixed cyclic order (all blocks of the MLP once per 32-sample chunk),
-// so the stream is a ring of NSLOT slots filled two blocks ahead by `global_load_lds_dwordx4` (no VGPR staging):
-// each of the 4 waves issues a quarter of a block's 1 KiB pieces.  Per block step:
-//     s_waitcnt vmcnt(#pieces of the NEXT block)   -> this wave's pieces of the CURRENT block have landed
-//     s_barrier                                    -> everyone's pieces landed; everyone is done reading the
-//                                                     previous block, whose slot is the one refilled next
-//     issue the DMA of block (current + 2)
-//     compute on the current slot
-// The DMA is inline asm on purpose: hipcc does not count it, so it neither drains it with vmcnt(0) at barriers nor
-// in front of unrelated LDS reads; our counted waits stay valid when compiler-issued loads/stores interleave
-// (extra younger operations only make `vmcnt(N)` stricter).
+// The packed image is a byte FIFO in consumption order, 2048 B per k-step (sunerf_common.h).  It is DMA'd page by
+// page (PAGE = one hidden tile = KS k-steps) into an LDS ring of 4 pages by `global_load_lds_dwordx4` (no VGPR
+// staging); each of the 4 waves moves a quarter of a page.  The stream length is a multiple of the ring size, so the
+// LDS address of k-step f of a pass is simply (2048 f) mod RING.  Page p+1 is ACQUIRED while page p is still being
+// read (PF k-steps before the reads cross into it):
+//     s_waitcnt vmcnt(pieces of one page)  -> this wave's pieces of page p+1 have landed (page p+2 may be in flight)
+//     s_barrier                            -> everyone's pieces landed; every wave is past page p-1
+//     issue the DMA of page p+3 into the slot page p-1 occupied
+// Ring occupancy at that moment: p (read), p+1 (landed), p+2 (in flight), p+3 (being issued) = 4 pages.
+// The DMA and its waits are inline asm on purpose: hipcc does not count them, so it neither drains them with
+// vmcnt(0) at barriers nor in front of unrelated LDS reads, and our counted waits stay valid when compiler-issued
+// loads/stores interleave (extra younger operations only make `vmcnt(N)` stricter).
 template <int D>
 struct Ring {
-  static constexpr int BLK0 = SUNERF_KS0 * 2048;
-  static constexpr int BLK = (D / 16) * 2048;
-  static constexpr int SLOT = BLK > BLK0 ? BLK : BLK0;   // ring slot size
-  static constexpr int CNT0 = BLK0 / 1024 / WAVES;   // DMA pieces per wave, in-layer block
-  static constexpr int CNT = BLK / 1024 / WAVES;     // hidden / out block
-  static_assert(BLK0 % (1024 * WAVES) == 0 && BLK % (1024 * WAVES) == 0, "blocks must split evenly over the waves");
-  const char* packed;
-  unsigned lds_base;   // LDS byte address of slot 0
-  int nb, nt;          // blocks per MLP pass, of which the first nt are in-layer blocks
-  int cur, pf;         // next block to consume / to prefetch (0..nb-1)
-  int cslot, pslot;    // their ring slots
-  int wave, lane;
+  static constexpr int KS = D / 16;
+  static constexpr int PAGE = KS * 2048;
+  static constexpr int RING = NSLOT * PAGE;
+  static constexpr int PIECES = PAGE / 1024 / WAVES;     // 1 KiB DMA instructions per wave and page
+  static_assert(NSLOT == 4 && PAGE % (1024 * WAVES) == 0, "page must split evenly over the waves");
+  const char* src;       // this wave's quarter of the next page to prefetch (wave-uniform)
+  const char* src_first; // ... of page 0
+  const char* src_end;   // ... one past the last page
+  unsigned dst;          // LDS byte address of this wave's quarter of the ring slot to fill next
+  unsigned dst_first;    // ... of slot 0
+  unsigned voff;         // lane * 16
+  int debug;
 
-  __device__ __forceinline__ void issue() {
-    const bool small = pf < nt;
-    const size_t off = small ? (size_t)pf * BLK0 : (size_t)nt * BLK0 + (size_t)(pf - nt) * BLK;
-    const int cnt = small ? CNT0 : CNT;
-    const char* src = packed + off + (size_t)(wave * cnt) * 1024 + lane * 16;
-    unsigned dst = lds_base + pslot * SLOT + wave * cnt * 1024;
-    for (int i = 0; i < cnt; ++i) {
-      unsigned keep;
-      const unsigned dst_u = __builtin_amdgcn_readfirstlane(dst);
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(src), "s"(dst_u) : "memory");
-      src += 1024; dst += 1024;
-    }
-    pf = (pf + 1 == nb) ? 0 : pf + 1;
-    pslot = (pslot + 1 == NSLOT) ? 0 : pslot + 1;
+  __device__ __forceinline__ void init(const char* packed, size_t stream_bytes, unsigned lds_base, int wave, int lane) {
+    const unsigned quarter = __builtin_amdgcn_readfirstlane(wave) * (PAGE / WAVES);
+    src_first = packed + quarter;
+    src_end = src_first + stream_bytes;
+    src = src_first;
+    dst_first = lds_base + quarter;
+    dst = dst_first;
+    voff = lane * 16;
+    debug = 0;
   }
-  __device__ __forceinline__ void prologue() { issue(); issue(); }
-  // returns the LDS byte offset (from slot 0) of the block to consume
-  __device__ __forceinline__ int acquire() {
-    const int nxt = (cur + 1 == nb) ? 0 : cur + 1;
-    if (nxt < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(CNT0) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(CNT) : "memory");
+  // DMA of one page (this wave's quarter): PIECES x 1 KiB.  The immediate offset of global_load_lds applies to the
+  // global AND the LDS address (measured), so up to four pieces share one M0 / base setting.
+  __device__ __forceinline__ void issue() {
+    if (!(debug & 1)) {
+#pragma unroll
+      for (int g = 0; g < PIECES; g += 4) {
+        const char* sg = src + g * 1024;
+        const unsigned dg = dst + g * 1024;
+        if (PIECES - g >= 4)
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                       "global_load_lds_dwordx4 %0, %2\n\tglobal_load_lds_dwordx4 %0, %2 offset:1024\n\t"
+                       "global_load_lds_dwordx4 %0, %2 offset:2048\n\tglobal_load_lds_dwordx4 %0, %2 offset:3072"
+                       :: "v"(voff), "s"(dg), "s"(sg) : "memory");
+        else
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                       "global_load_lds_dwordx4 %0, %2\n\tglobal_load_lds_dwordx4 %0, %2 offset:1024"
+                       :: "v"(voff), "s"(dg), "s"(sg) : "memory");
+      }
+    }
+    src += PAGE;
+    if (src == src_end) src = src_first;
+    dst += PAGE;
+    if (dst == dst_first + RING) dst = dst_first;
+  }
+  // makes the next page readable
+  __device__ __forceinline__ void acquire() {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PIECES) : "memory");
     __builtin_amdgcn_s_barrier();
     issue();
-    const int off = cslot * SLOT;
-    cur = nxt;
-    cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
-    return off;
   }
 };
 
-// one 32-row output tile: acc = bias + W_tile * X   (three fp16 MFMAs per k-step)
-template <int KSTEPS>
-__device__ __forceinline__ f32x16 tile_mma(const char* slot, const float* bias_tile, int lane, int h,
-                                           const half8* xhi, const half8* xlo) {
+// Register plan (512 unified registers per lane, one wave per SIMD): the two activation fragment sets (layer input
+// and layer output, 2 x 128 registers at D = 256) live in the ACCUMULATION half of the register file -- MFMA reads
+// its B operand from AGPRs directly -- which leaves the 256 architectural VGPRs for the fp32 accumulators (two
+// tiles in flight), a multi-k-step ring of A fragments and the epilogue temporaries.  `pin_agpr` is an empty asm
+// that makes a freshly produced fragment live in AGPRs (the allocator then keeps it there for the MFMAs).
+__device__ __forceinline__ void pin_agpr(half8& f) { asm volatile("" : "+a"(f)); }
+
+// sin (argument in revolutions: the 1/(2 pi) is folded into the packed weights) + hi/lo split of accumulator elements
+// (2p, 2p+1) into fragment elements: one "micro-op" of a tile's epilogue, issued in the MFMA shadow of the next tile
+__device__ __forceinline__ void activate_pair(const f32x16& acc, int p, half8& hi0, half8& lo0, half8& hi1, half8& lo1) {
+  half2v a, b;
+  split2(__builtin_amdgcn_sinf(acc[2 * p]), __builtin_amdgcn_sinf(acc[2 * p + 1]), a, b);
+  // anchor: the packed results must exist HERE (in this k-step's issue slots); without it the optimiser sinks the
+  // whole epilogue to its only consumer, the end of the tile, where it would run unoverlapped
+  asm volatile("" : "+v"(a), "+v"(b));
+  if (p < 4) { hi0[2 * p] = a[0]; hi0[2 * p + 1] = a[1]; lo0[2 * p] = b[0]; lo0[2 * p + 1] = b[1]; }
+  else { hi1[2 * p - 8] = a[0]; hi1[2 * p - 7] = a[1]; lo1[2 * p - 8] = b[0]; lo1[2 * p - 7] = b[1]; }
+  if (p == 3) { pin_agpr(hi0); pin_agpr(lo0); }
+  if (p == 7) { pin_agpr(hi1); pin_agpr(lo1); }
+}
+
+__device__ __forceinline__ f32x16 bias_tile(const float* bias, int h) {
   f32x16 acc;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const f32x4 b = *(const f32x4*)(bias_tile + 8 * j + 4 * h);
+    const f32x4 b = *(const f32x4*)(bias + 8 * j + 4 * h);
     acc[4 * j + 0] = b[0]; acc[4 * j + 1] = b[1]; acc[4 * j + 2] = b[2]; acc[4 * j + 3] = b[3];
-  }
-#pragma unroll
-  for (int s = 0; s < KSTEPS; ++s) {
-    const half8 ahi = *(const half8*)(slot + s * 2048 + lane * 16);
-    const half8 alo = *(const half8*)(slot + s * 2048 + 1024 + lane * 16);
-    acc = mfma16(alo, xhi[s], acc);
-    acc = mfma16(ahi, xlo[s], acc);
-    acc = mfma16(ahi, xhi[s], acc);
   }
   return acc;
 }
 
-// sin() + hi/lo split of one accumulator tile into the two k-step fragments it forms for the next layer
-__device__ __forceinline__ void activate_tile(const f32x16& acc, half8& hi0, half8& lo0, half8& hi1, half8& lo1) {
-#pragma unroll
-  for (int j = 0; j < 8; j += 2) {
-    half2v a, b;
-    split2(sin_rad(acc[j]), sin_rad(acc[j + 1]), a, b);
-    hi0[j] = a[0]; hi0[j + 1] = a[1]; lo0[j] = b[0]; lo0[j + 1] = b[1];
-    split2(sin_rad(acc[8 + j]), sin_rad(acc[8 + j + 1]), a, b);
-    hi1[j] = a[0]; hi1[j + 1] = a[1]; lo1[j] = b[0]; lo1[j + 1] = b[1];
-  }
-}
-
+// The MLP as ONE software pipeline over k-steps that runs across tiles, layers, chunks and rays: the A fragments
+// (hi, lo: one ds_read_b128 each) of k-step f + PF are requested while the three MFMAs of k-step f issue, so LDS
+// latency is always covered by matrix work, and the VALU epilogue of tile U-1 (sin, split, pack) is dealt out over
+// the first k-steps of tile U.  One wave issues at most one instruction per ~4 cycles, so the per-k-step order is
+// pinned with sched_group_barrier: MFMA, a few VALU, a DS read, ... instead of leaving the epilogue as one clump
+// between two tiles.
 template <int D>
 struct Mlp {
   static constexpr int NT = D / 32;
   static constexpr int KS = D / 16;
   static constexpr int XK = KS > SUNERF_KS0 ? KS : SUNERF_KS0;  // fragments per register set
-  static constexpr int BLK0 = SUNERF_KS0 * 2048;
-  static constexpr int BLK = KS * 2048;
+  static constexpr int PF = 4;                                   // prefetch distance in k-steps
+  static constexpr int PAGE_STEPS = KS;                          // k-steps per DMA page
+  static constexpr int RING_STEPS = NSLOT * KS;
+  static_assert(KS >= PF && SUNERF_KS0 >= PF, "prefetch distance exceeds a tile");
+  static_assert((NT * SUNERF_KS0) % PF == 0 && KS % PF == 0, "fragment ring phase must be 0 at every layer start");
+  static_assert((NT * SUNERF_KS0) % KS == 0, "the in layer must end on a page boundary");
+  // D >= 128: a hidden layer is a whole number of ring revolutions and a pass ends where it began, so the ring
+  // position of every k-step is a compile-time constant (immediate ds_read offsets).  D = 64: tracked at run time.
+  static constexpr bool STATIC_RING = (NT * KS) % RING_STEPS == 0 && (NT * SUNERF_KS0 + KS) % RING_STEPS == 0;
+  static constexpr int RS_HIDDEN = STATIC_RING ? (NT * SUNERF_KS0) % RING_STEPS : -1;   // ring step where hidden layers start
+  static constexpr int RS_IN = STATIC_RING ? 0 : -1;
 
-  // one layer: X (KIN k-steps) -> Y (KS k-steps); weight blocks come through the LDS ring
-  template <int KIN>
-  static __device__ __forceinline__ void layer(Ring<D>& ring, const char* slots, const float* bias, int lane, int h,
-                                               const half8* xhi, const half8* xlo, half8* yhi, half8* ylo) {
-#pragma unroll
-    for (int U = 0; U < NT; ++U) {
-      const char* slot = slots + ring.acquire();
-      const f32x16 acc = tile_mma<KIN>(slot, bias + 32 * U, lane, h, xhi, xlo);
-      activate_tile(acc, yhi[2 * U], ylo[2 * U], yhi[2 * U + 1], ylo[2 * U + 1]);
-    }
+  struct Pipe {
+    half8 ahi[PF], alo[PF];   // fragments of the next PF k-steps
+    const char* frag;         // LDS address (lane-adjusted) of ring offset 0
+    int rstep;                // ring position (in k-steps, 0..RING_STEPS-1) of the NEXT k-step to execute
+  };
+
+  static __device__ __forceinline__ void load_frag(Pipe& p, int r, int ring_step) {
+    const char* q = p.frag + ring_step * 2048;
+    p.ahi[r] = *(const half8*)(q);
+    p.alo[r] = *(const half8*)(q + 1024);
   }
 
-  static __device__ __forceinline__ f32x16 out_layer(Ring<D>& ring, const char* slots, const float* bias, int lane,
-                                                     int h, const half8* xhi, const half8* xlo) {
-    const char* slot = slots + ring.acquire();
-    return tile_mma<KS>(slot, bias, lane, h, xhi, xlo);
+  // before the first k-step of the first chunk: pages 0 and 1 in flight, page 0 acquired, first PF k-steps requested
+  static __device__ __forceinline__ void start(Ring<D>& ring, Pipe& p) {
+    ring.issue();
+    ring.issue();
+    ring.acquire();
+    p.rstep = 0;
+#pragma unroll
+    for (int s = 0; s < PF; ++s) load_frag(p, s, s);
+  }
+
+  // k-steps of one tile.  T0 = stream position (in k-steps) of the tile's first k-step relative to a page boundary
+  // (tiles of the in layer are 6 k-steps and straddle pages; all other tiles start on a page boundary).
+  // `prev`: accumulator of the previous tile whose epilogue is interleaved here (HAS_PREV), writing y*.
+  template <int KIN, int T0, bool HAS_PREV, int RS0>
+  static __device__ __forceinline__ f32x16 tile(Ring<D>& ring, Pipe& p, f32x16 acc, const half8* xhi, const half8* xlo,
+                                                const f32x16& prev, half8& yh0, half8& yl0, half8& yh1, half8& yl1) {
+    // k-steps that carry epilogue micro-ops.  For the first tile of a layer the epilogue produces the layer's own last
+    // two input fragments (read by k-steps KIN-2 and KIN-1), so it must be complete before k-step KIN-2.
+    constexpr int EPI_STEPS = (KIN - 2) >= 8 ? 8 : (KIN - 2);
+    static_assert(EPI_STEPS >= 1, "tile too short to hide the previous tile's epilogue");
+#pragma unroll
+    for (int s = 0; s < KIN; ++s) {
+      const int r = (T0 + s) % PF;
+      acc = mfma16(p.alo[r], xhi[s], acc);
+      acc = mfma16(p.ahi[r], xlo[s], acc);
+      acc = mfma16(p.ahi[r], xhi[s], acc);
+      if ((T0 + s + PF) % PAGE_STEPS == 0) ring.acquire();   // the reads below cross into the next page
+      if (RS0 >= 0) {
+        load_frag(p, r, (RS0 + s + PF) % RING_STEPS);
+      } else {
+        int rs = p.rstep + s + PF;
+        rs = rs >= RING_STEPS ? rs - RING_STEPS : rs;
+        load_frag(p, r, rs);
+      }
+      if (HAS_PREV) {
+        // 8 pairs over EPI_STEPS k-steps
+        constexpr int per = (8 + EPI_STEPS - 1) / EPI_STEPS;
+#pragma unroll
+        for (int q = 0; q < per; ++q) {
+          const int pair = s * per + q;
+          if (s < EPI_STEPS && pair < 8) activate_pair(prev, pair, yh0, yl0, yh1, yl1);
+        }
+      }
+      // pin the issue order of this k-step: MFMA | VALU.. | DS | MFMA | VALU.. | DS | MFMA | VALU..
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (RS0 < 0) {
+      p.rstep += KIN;
+      if (p.rstep >= RING_STEPS) p.rstep -= RING_STEPS;
+    }
+    return acc;
+  }
+
+  // one layer: X (KIN k-steps) -> Y (KS k-steps).  `carry` is the accumulator of the previous layer's last tile,
+  // whose epilogue (into that layer's output set = our X, fragments 2*NT-2, 2*NT-1) overlaps our first tile: those
+  // fragments are only read by our last two k-steps.  Returns our own last accumulator the same way.
+  template <int KIN, bool HAS_CARRY, int RSL0>
+  static __device__ __forceinline__ f32x16 layer(Ring<D>& ring, Pipe& p, const float* bias, int h, half8* xhi, half8* xlo,
+                                                 half8* yhi, half8* ylo, const f32x16& carry) {
+    f32x16 prev = carry;
+#pragma unroll
+    for (int U = 0; U < NT; ++U) {
+      f32x16 acc = bias_tile(bias + 32 * U, h);
+      constexpr int XL = 2 * NT - 2;   // previous layer's last tile -> our X fragments
+#define SUNERF_TILE(UU)                                                                                        \
+      if (U == UU) {                                                                                             \
+        constexpr int RS = RSL0 < 0 ? -1 : (RSL0 + UU * KIN) % RING_STEPS;                                       \
+        if (UU == 0) acc = tile<KIN, (UU * KIN) % KS, HAS_CARRY, RS>(ring, p, acc, xhi, xlo, prev, xhi[XL], xlo[XL], xhi[XL + 1], xlo[XL + 1]); \
+        else acc = tile<KIN, (UU * KIN) % KS, true, RS>(ring, p, acc, xhi, xlo, prev, yhi[2 * UU - 2], ylo[2 * UU - 2], yhi[2 * UU - 1], ylo[2 * UU - 1]); \
+      }
+      SUNERF_TILE(0) SUNERF_TILE(1) SUNERF_TILE(2) SUNERF_TILE(3) SUNERF_TILE(4) SUNERF_TILE(5) SUNERF_TILE(6) SUNERF_TILE(7)
+#undef SUNERF_TILE
+      prev = acc;
+    }
+    return prev;
+  }
+
+  static __device__ __forceinline__ f32x16 out_layer(Ring<D>& ring, Pipe& p, const float* bias, int h, half8* xhi,
+                                                     half8* xlo, const f32x16& carry) {
+    constexpr int XL = 2 * NT - 2;
+    return tile<KS, 0, true, RS_HIDDEN>(ring, p, bias_tile(bias, h), xhi, xlo, carry, xhi[XL], xlo[XL], xhi[XL + 1], xlo[XL + 1]);
   }
 };
 
@@ -217,8 +329,8 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
   using M = Mlp<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const PackedLayout L(D, a.n_linear);
-  char* slot = smem;                                            // ring of NSLOT weight-block slots
-  float* bias = (float*)(smem + (size_t)NSLOT * Ring<D>::SLOT);  // n_bias floats
+  char* slot = smem;                                            // ring of NSLOT weight pages
+  float* bias = (float*)(smem + (size_t)Ring<D>::RING);          // n_bias floats
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, h = lane >> 5;
@@ -229,13 +341,11 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
   }
   __syncthreads();
   Ring<D> ring;
-  ring.packed = a.packed;
-  ring.lds_base = (unsigned)(uintptr_t)slot;
-  ring.nt = M::NT;
-  ring.nb = M::NT * (a.n_linear - 1) + 1;
-  ring.cur = 0; ring.pf = 0; ring.cslot = 0; ring.pslot = 0;
-  ring.wave = __builtin_amdgcn_readfirstlane(wave); ring.lane = lane;
-  ring.prologue();
+  ring.init(a.packed, L.stream_bytes(), (unsigned)(uintptr_t)slot, wave, lane);
+  typename M::Pipe pipe;
+  pipe.frag = slot + lane * 16;
+  M::start(ring, pipe);
+  ring.debug = a.debug;
   const int S = a.S;
   const int n_chunks = (S + 31) >> 5;
   const int64_t n_groups = (a.n_rays + WAVES - 1) / WAVES;
@@ -269,22 +379,25 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
           xb_hi[q >> 3][q & 7] = hi;
           xb_lo[q >> 3][q & 7] = (_Float16)(val - (float)hi);
         });
+#pragma unroll
+        for (int s = 0; s < SUNERF_KS0; ++s) { pin_agpr(xb_hi[s]); pin_agpr(xb_lo[s]); }
       }
       // in layer: 84(96) -> D
-      M::template layer<SUNERF_KS0>(ring, slot, bias, lane, h, xb_hi, xb_lo, xa_hi, xa_lo);
+      f32x16 carry = {0};
+      carry = M::template layer<SUNERF_KS0, false, M::RS_IN>(ring, pipe, bias, h, xb_hi, xb_lo, xa_hi, xa_lo, carry);
       // hidden layers, ping-pong between the two register sets
       int l = 1;
       for (; l + 1 < a.n_linear - 1; l += 2) {
-        M::template layer<M::KS>(ring, slot, bias + (size_t)l * D, lane, h, xa_hi, xa_lo, xb_hi, xb_lo);
-        M::template layer<M::KS>(ring, slot, bias + (size_t)(l + 1) * D, lane, h, xb_hi, xb_lo, xa_hi, xa_lo);
+        carry = M::template layer<M::KS, true, M::RS_HIDDEN>(ring, pipe, bias + (size_t)l * D, h, xa_hi, xa_lo, xb_hi, xb_lo, carry);
+        carry = M::template layer<M::KS, true, M::RS_HIDDEN>(ring, pipe, bias + (size_t)(l + 1) * D, h, xb_hi, xb_lo, xa_hi, xa_lo, carry);
       }
       f32x16 out;
       const float* obias = bias + (size_t)(a.n_linear - 1) * D;
       if (l < a.n_linear - 1) {
-        M::template layer<M::KS>(ring, slot, bias + (size_t)l * D, lane, h, xa_hi, xa_lo, xb_hi, xb_lo);
-        out = M::out_layer(ring, slot, obias, lane, h, xb_hi, xb_lo);
+        carry = M::template layer<M::KS, true, M::RS_HIDDEN>(ring, pipe, bias + (size_t)l * D, h, xa_hi, xa_lo, xb_hi, xb_lo, carry);
+        out = M::out_layer(ring, pipe, obias, h, xb_hi, xb_lo, carry);
       } else {
-        out = M::out_layer(ring, slot, obias, lane, h, xa_hi, xa_lo);
+        out = M::out_layer(ring, pipe, obias, h, xa_hi, xa_lo, carry);
       }
 
       // ---- emission / absorption integral for this chunk (emission.py:14-54); lanes 0..31 hold rows 0,1 ----
@@ -347,7 +460,7 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
 template <int D>
 int launch_render(const RenderArgs& a, hipStream_t stream) {
   const PackedLayout L(D, a.n_linear);
-  const size_t lds = (size_t)NSLOT * Ring<D>::SLOT + L.n_bias() * 4;
+  const size_t lds = (size_t)Ring<D>::RING + L.n_bias() * 4;
   if (lds > 160 * 1024) return SUNERF_E_UNSUPPORTED;
   hipError_t e = hipFuncSetAttribute((const void*)render_fwd_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
@@ -384,6 +497,8 @@ extern "C" int sunerf_emission_render_fwd(const void* packed, int d_filter, int 
   a.n_rays = n_rays; a.S = n_samples; a.n_linear = n_linear; a.image = image; a.weights = weights;
   a.absorption = absorption; a.raw = raw; a.height_map = height_map; a.absorption_map = absorption_map;
   a.regularization = regularization; a.reg_radius = reg_radius; a.stash = (char*)act_stash;
+  const char* dbg = getenv("SUNERF_DEBUG");
+  a.debug = dbg ? atoi(dbg) : 0;
   switch (d_filter) {
     case 64: return launch_render<64>(a, (hipStream_t)stream);
     case 128: return launch_render<128>(a, (hipStream_t)stream);

@@ -25,8 +25,16 @@
 //       q >= 44     : zero
 //
 // Byte layout of the packed image for (D = d_filter, n_linear Linear layers):
-//   [in_layer : D/32 blocks of 6*2048 B][hidden l=1..n_linear-2 : D/32 blocks of (D/16)*2048 B each]
-//   [out_layer: 1 block of (D/16)*2048 B, rows >= d_out zero][bias fp32: (n_linear-1)*D, then 32 (out layer)]
+//   weight STREAM, in consumption order, every k-step exactly 2048 B (hi fragment, lo fragment):
+//     [in_layer : D/32 tiles x 6 k-steps][hidden l=1..n_linear-2 : D/32 tiles x D/16 k-steps each]
+//     [out_layer: 1 tile x D/16 k-steps, rows >= d_out zero]
+//   then [bias fp32: (n_linear-1)*D, then 32 (out layer)]
+//   The render kernels treat the stream as a byte FIFO that is DMA'd page by page (page = (D/16)*2048 B) into an
+//   LDS ring of 4 pages; the stream length is a multiple of the page size (and, for D >= 128, of the ring size, so
+//   that every MLP pass starts at ring offset 0 and all LDS read addresses are compile-time constants).
+//   All layers except out_layer are stored pre-multiplied by 1/(2 pi) (weights and biases): the accumulator then
+//   holds the pre-activation in REVOLUTIONS, which is what the hardware v_sin_f32 takes -- one multiply per
+//   activation saved.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -51,7 +59,10 @@ struct PackedLayout {
     if (l < n_linear - 1) return base + ((size_t)(l - 1) * NT + U) * blk;
     return base + (size_t)(n_linear - 2) * NT * blk;
   }
-  __host__ __device__ size_t bias_off() const { return (size_t)NT * blk0 + (size_t)(n_linear - 2) * NT * blk + blk; }
+  __host__ __device__ size_t pass_bytes() const { return (size_t)NT * blk0 + (size_t)(n_linear - 2) * NT * blk + blk; }
+  __host__ __device__ size_t ring_bytes() const { return 4 * blk; }
+  __host__ __device__ size_t stream_bytes() const { return pass_bytes(); }   // always a multiple of the page size
+  __host__ __device__ size_t bias_off() const { return stream_bytes(); }
   __host__ __device__ size_t n_bias() const { return (size_t)(n_linear - 1) * D + 32; }
   __host__ __device__ size_t total_bytes() const { return bias_off() + n_bias() * 4; }
 };
