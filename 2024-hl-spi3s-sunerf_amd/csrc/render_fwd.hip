@@ -40,7 +40,6 @@ struct RenderArgs {
   float* regularization;
   float reg_radius;
   char* stash;
-  int debug;   // development ablations (SUNERF_DEBUG env): 1 = no weight DMA after the prologue (results invalid)
 };
 
 __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
@@ -104,8 +103,8 @@ __device__ __forceinline__ float shfl_up32(float v, int d, int n) {  // within t
 // read (PF k-steps before the reads cross into it):
 //     s_waitcnt vmcnt(pieces of one page)  -> this wave's pieces of page p+1 have landed (page p+2 may be in flight)
 //     s_barrier                            -> everyone's pieces landed; every wave is past page p-1
-//     issue the DMA of page p+3 into the slot page p-1 occupied
-// Ring occupancy at that moment: p (read), p+1 (landed), p+2 (in flight), p+3 (being issued) = 4 pages.
+//     then, one piece per k-step: the DMA of page p+3 into the slot page p-1 occupied
+// Ring occupancy: p (read), p+1 (landed), p+2 (in flight), p+3 (being issued) = 4 pages.
 // The DMA and its waits are inline asm on purpose: hipcc does not count them, so it neither drains them with
 // vmcnt(0) at barriers nor in front of unrelated LDS reads, and our counted waits stay valid when compiler-issued
 // loads/stores interleave (extra younger operations only make `vmcnt(N)` stricter).
@@ -122,7 +121,6 @@ struct Ring {
   unsigned dst;          // LDS byte address of this wave's quarter of the ring slot to fill next
   unsigned dst_first;    // ... of slot 0
   unsigned voff;         // lane * 16
-  int debug;
 
   __device__ __forceinline__ void init(const char* packed, size_t stream_bytes, unsigned lds_base, int wave, int lane) {
     const unsigned quarter = __builtin_amdgcn_readfirstlane(wave) * (PAGE / WAVES);
@@ -132,37 +130,41 @@ struct Ring {
     dst_first = lds_base + quarter;
     dst = dst_first;
     voff = lane * 16;
-    debug = 0;
   }
-  // DMA of one page (this wave's quarter): PIECES x 1 KiB.  The immediate offset of global_load_lds applies to the
-  // global AND the LDS address (measured), so up to four pieces share one M0 / base setting.
-  __device__ __forceinline__ void issue() {
-    if (!(debug & 1)) {
-#pragma unroll
-      for (int g = 0; g < PIECES; g += 4) {
-        const char* sg = src + g * 1024;
-        const unsigned dg = dst + g * 1024;
-        if (PIECES - g >= 4)
-          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
-                       "global_load_lds_dwordx4 %0, %2\n\tglobal_load_lds_dwordx4 %0, %2 offset:1024\n\t"
-                       "global_load_lds_dwordx4 %0, %2 offset:2048\n\tglobal_load_lds_dwordx4 %0, %2 offset:3072"
-                       :: "v"(voff), "s"(dg), "s"(sg) : "memory");
-        else
-          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
-                       "global_load_lds_dwordx4 %0, %2\n\tglobal_load_lds_dwordx4 %0, %2 offset:1024"
-                       :: "v"(voff), "s"(dg), "s"(sg) : "memory");
-      }
+  // DMA of piece j (1 KiB) of this wave's quarter of the page being prefetched.  The immediate offset of
+  // global_load_lds applies to the global AND the LDS address (measured), so src/dst only move in 4 KiB strides.
+  // The pieces of a page are dealt out one per k-step between two acquires instead of being issued as a burst right
+  // behind the barrier: 4 waves x 8 KiB arriving together would collide with the fragment reads of all four waves.
+  template <int J>
+  __device__ __forceinline__ void issue_piece() {
+    static_assert(J >= 0 && J < PIECES, "piece index");
+#ifndef SUNERF_ABL_NODMA
+    {
+      const char* sg = src + (J / 4) * 4096;
+      const unsigned dg = dst + (J / 4) * 4096;
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 offset:%3"
+                   :: "v"(voff), "s"(dg), "s"(sg), "i"((J % 4) * 1024) : "memory");
     }
-    src += PAGE;
-    if (src == src_end) src = src_first;
-    dst += PAGE;
-    if (dst == dst_first + RING) dst = dst_first;
+#endif
+    if (J == PIECES - 1) {   // page complete: advance to the next page / ring slot
+      src += PAGE;
+      if (src == src_end) src = src_first;
+      dst += PAGE;
+      if (dst == dst_first + RING) dst = dst_first;
+    }
   }
-  // makes the next page readable
+  template <int J = 0>
+  __device__ __forceinline__ void issue_page() {
+    issue_piece<J>();
+    if constexpr (J + 1 < PIECES) issue_page<J + 1>();
+  }
+  // makes the next page readable: this wave's pieces of it have landed (the PIECES younger ones, of the page after
+  // it, may still be in flight), then everyone's
   __device__ __forceinline__ void acquire() {
     asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PIECES) : "memory");
+#ifndef SUNERF_ABL_NOBARRIER
     __builtin_amdgcn_s_barrier();
-    issue();
+#endif
   }
 };
 
@@ -173,16 +175,36 @@ struct Ring {
 // that makes a freshly produced fragment live in AGPRs (the allocator then keeps it there for the MFMAs).
 __device__ __forceinline__ void pin_agpr(half8& f) { asm volatile("" : "+a"(f)); }
 
-// sin (argument in revolutions: the 1/(2 pi) is folded into the packed weights) + hi/lo split of accumulator elements
-// (2p, 2p+1) into fragment elements: one "micro-op" of a tile's epilogue, issued in the MFMA shadow of the next tile
-__device__ __forceinline__ void activate_pair(const f32x16& acc, int p, half8& hi0, half8& lo0, half8& hi1, half8& lo1) {
-  half2v a, b;
-  split2(__builtin_amdgcn_sinf(acc[2 * p]), __builtin_amdgcn_sinf(acc[2 * p + 1]), a, b);
-  // anchor: the packed results must exist HERE (in this k-step's issue slots); without it the optimiser sinks the
-  // whole epilogue to its only consumer, the end of the tile, where it would run unoverlapped
-  asm volatile("" : "+v"(a), "+v"(b));
-  if (p < 4) { hi0[2 * p] = a[0]; hi0[2 * p + 1] = a[1]; lo0[2 * p] = b[0]; lo0[2 * p + 1] = b[1]; }
-  else { hi1[2 * p - 8] = a[0]; hi1[2 * p - 7] = a[1]; lo1[2 * p - 8] = b[0]; lo1[2 * p - 7] = b[1]; }
+// Epilogue of one accumulator tile = 8 "pair" micro-ops (elements 2p, 2p+1 -> one dword of a hi and of a lo fragment),
+// each cut into three stages that are issued behind the three MFMAs of a k-step of the NEXT tile:
+//   A: sin (argument in revolutions: the 1/(2 pi) is folded into the packed weights)
+//   B: hi = fp16(x) (packed), remainder x - hi
+//   C: lo = fp16(remainder) (packed), insert into the fragments
+// The empty asm statements anchor every stage where it is written: without them the optimiser sinks the whole
+// epilogue to its only consumer (the end of the tile), where it would run unoverlapped with matrix work.
+struct PairTmp {
+  float s0, s1, r0, r1;
+  half2v hi;
+};
+__device__ __forceinline__ void epi_stage_a(const f32x16& acc, int p, PairTmp& t) {
+  t.s0 = __builtin_amdgcn_sinf(acc[2 * p]);
+  t.s1 = __builtin_amdgcn_sinf(acc[2 * p + 1]);
+  asm volatile("" : "+v"(t.s0), "+v"(t.s1));
+}
+__device__ __forceinline__ void epi_stage_b(PairTmp& t) {
+  const f32x2 sv = {t.s0, t.s1};
+  t.hi = __builtin_convertvector(sv, half2v);   // one v_cvt_pk_f16_f32 (round to nearest even)
+  asm volatile("" : "+v"(t.hi));                 // ... and convert back from the packed word, not from two scalar casts
+  t.r0 = t.s0 - (float)t.hi[0];
+  t.r1 = t.s1 - (float)t.hi[1];
+  asm volatile("" : "+v"(t.hi), "+v"(t.r0), "+v"(t.r1));
+}
+__device__ __forceinline__ void epi_stage_c(const PairTmp& t, int p, half8& hi0, half8& lo0, half8& hi1, half8& lo1) {
+  half2v lo;
+  lo[0] = (_Float16)t.r0; lo[1] = (_Float16)t.r1;
+  if (p < 4) { hi0[2 * p] = t.hi[0]; hi0[2 * p + 1] = t.hi[1]; lo0[2 * p] = lo[0]; lo0[2 * p + 1] = lo[1]; }
+  else { hi1[2 * p - 8] = t.hi[0]; hi1[2 * p - 7] = t.hi[1]; lo1[2 * p - 8] = lo[0]; lo1[2 * p - 7] = lo[1]; }
+  // (pinning after every insertion instead makes hipcc rewrite the whole 4-dword tuple each time: measured worse)
   if (p == 3) { pin_agpr(hi0); pin_agpr(lo0); }
   if (p == 7) { pin_agpr(hi1); pin_agpr(lo1); }
 }
@@ -226,6 +248,21 @@ struct Mlp {
     int rstep;                // ring position (in k-steps, 0..RING_STEPS-1) of the NEXT k-step to execute
   };
 
+  static __device__ __forceinline__ void issue_piece_dyn(Ring<D>& ring, int j) {   // j is a constant after unrolling
+    if (j == 0) ring.template issue_piece<0>();
+    if (j == 1) ring.template issue_piece<1>();
+    if constexpr (Ring<D>::PIECES > 2) {
+      if (j == 2) ring.template issue_piece<2>();
+      if (j == 3) ring.template issue_piece<3>();
+    }
+    if constexpr (Ring<D>::PIECES > 4) {
+      if (j == 4) ring.template issue_piece<4>();
+      if (j == 5) ring.template issue_piece<5>();
+      if (j == 6) ring.template issue_piece<6>();
+      if (j == 7) ring.template issue_piece<7>();
+    }
+  }
+
   static __device__ __forceinline__ void load_frag(Pipe& p, int r, int ring_step) {
     const char* q = p.frag + ring_step * 2048;
     p.ahi[r] = *(const half8*)(q);
@@ -234,9 +271,15 @@ struct Mlp {
 
   // before the first k-step of the first chunk: pages 0 and 1 in flight, page 0 acquired, first PF k-steps requested
   static __device__ __forceinline__ void start(Ring<D>& ring, Pipe& p) {
-    ring.issue();
-    ring.issue();
+    ring.template issue_page<0>();
+    ring.template issue_page<0>();
     ring.acquire();
+    // the pass starts at page phase 0, i.e. in the middle of a trickle cycle that began at the acquire phase: deal out
+    // the pieces of page 2 that the k-steps between the acquire phase and the page end would have issued
+    constexpr int ACQ = (PAGE_STEPS - PF) % PAGE_STEPS;
+#pragma unroll
+    for (int j = 0; j < Ring<D>::PIECES; ++j)
+      if (ACQ + 1 + 2 * j < PAGE_STEPS) issue_piece_dyn(ring, j);
     p.rstep = 0;
 #pragma unroll
     for (int s = 0; s < PF; ++s) load_frag(p, s, s);
@@ -252,38 +295,60 @@ struct Mlp {
     // two input fragments (read by k-steps KIN-2 and KIN-1), so it must be complete before k-step KIN-2.
     constexpr int EPI_STEPS = (KIN - 2) >= 8 ? 8 : (KIN - 2);
     static_assert(EPI_STEPS >= 1, "tile too short to hide the previous tile's epilogue");
+    constexpr int PER = (8 + EPI_STEPS - 1) / EPI_STEPS;   // pair micro-ops per k-step
 #pragma unroll
     for (int s = 0; s < KIN; ++s) {
       const int r = (T0 + s) % PF;
+      PairTmp t[PER];
+      // --- MFMA 1 | stage A --------------------------------------------------------------------------------
       acc = mfma16(p.alo[r], xhi[s], acc);
+#ifndef SUNERF_ABL_NOEPI
+      if (HAS_PREV) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+          if (s * PER + q < 8) epi_stage_a(prev, s * PER + q, t[q]);
+      }
+#else
+      if (HAS_PREV && s == 0) asm volatile("" :: "v"(prev));   // ablation: keep the MFMA chain alive
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      // --- MFMA 2 | stage B --------------------------------------------------------------------------------
       acc = mfma16(p.ahi[r], xlo[s], acc);
+#ifndef SUNERF_ABL_NOEPI
+      if (HAS_PREV) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+          if (s * PER + q < 8) epi_stage_b(t[q]);
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      // --- MFMA 3 | stage C | next page | A-fragment reads of k-step s + PF --------------------------------------
       acc = mfma16(p.ahi[r], xhi[s], acc);
-      if ((T0 + s + PF) % PAGE_STEPS == 0) ring.acquire();   // the reads below cross into the next page
+#ifndef SUNERF_ABL_NOEPI
+      if (HAS_PREV) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+          if (s * PER + q < 8) epi_stage_c(t[q], s * PER + q, yh0, yl0, yh1, yl1);
+      }
+#endif
+      {
+        constexpr int ACQ = (PAGE_STEPS - PF) % PAGE_STEPS;          // page phase at which the next page is acquired
+        const int phase = (T0 + s) % PAGE_STEPS;
+        if (phase == ACQ) ring.acquire();                            // the reads below cross into the next page
+        const int rel = (phase - ACQ - 1 + PAGE_STEPS) % PAGE_STEPS; // k-steps since the acquire, minus one
+        if (rel % 2 == 0 && rel / 2 < Ring<D>::PIECES) issue_piece_dyn(ring, rel / 2);
+      }
+#ifdef SUNERF_ABL_NOLDS
+      if (false) {
+#else
       if (RS0 >= 0) {
+#endif
         load_frag(p, r, (RS0 + s + PF) % RING_STEPS);
-      } else {
+      } else if (RS0 < 0) {
         int rs = p.rstep + s + PF;
         rs = rs >= RING_STEPS ? rs - RING_STEPS : rs;
         load_frag(p, r, rs);
       }
-      if (HAS_PREV) {
-        // 8 pairs over EPI_STEPS k-steps
-        constexpr int per = (8 + EPI_STEPS - 1) / EPI_STEPS;
-#pragma unroll
-        for (int q = 0; q < per; ++q) {
-          const int pair = s * per + q;
-          if (s < EPI_STEPS && pair < 8) activate_pair(prev, pair, yh0, yl0, yh1, yl1);
-        }
-      }
-      // pin the issue order of this k-step: MFMA | VALU.. | DS | MFMA | VALU.. | DS | MFMA | VALU..
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (RS0 < 0) {
@@ -345,7 +410,6 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
   typename M::Pipe pipe;
   pipe.frag = slot + lane * 16;
   M::start(ring, pipe);
-  ring.debug = a.debug;
   const int S = a.S;
   const int n_chunks = (S + 31) >> 5;
   const int64_t n_groups = (a.n_rays + WAVES - 1) / WAVES;
@@ -466,8 +530,8 @@ int launch_render(const RenderArgs& a, hipStream_t stream) {
   if (e != hipSuccess) return (int)e;
   const int64_t n_groups = (a.n_rays + WAVES - 1) / WAVES;
   int dev = 0, cus = 256;
-  hipGetDevice(&dev);
-  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const unsigned grid = (unsigned)(n_groups < cus ? n_groups : cus);
   SUNERF_CLEAR_ERROR();
   hipLaunchKernelGGL(render_fwd_kernel<D>, dim3(grid), dim3(THREADS), lds, stream, a);
@@ -497,8 +561,6 @@ extern "C" int sunerf_emission_render_fwd(const void* packed, int d_filter, int 
   a.n_rays = n_rays; a.S = n_samples; a.n_linear = n_linear; a.image = image; a.weights = weights;
   a.absorption = absorption; a.raw = raw; a.height_map = height_map; a.absorption_map = absorption_map;
   a.regularization = regularization; a.reg_radius = reg_radius; a.stash = (char*)act_stash;
-  const char* dbg = getenv("SUNERF_DEBUG");
-  a.debug = dbg ? atoi(dbg) : 0;
   switch (d_filter) {
     case 64: return launch_render<64>(a, (hipStream_t)stream);
     case 128: return launch_render<128>(a, (hipStream_t)stream);

@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (side effect: loads torch's HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libsunerf_hip.so')
+LIB_PATH = os.environ.get('SUNERF_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'libsunerf_hip.so')
 
 _lib = None
 
