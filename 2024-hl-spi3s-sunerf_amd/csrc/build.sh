@@ -3,9 +3,16 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libsunerf_hip.so
-# -amdgpu-mfma-vgpr-form: MFMA accumulators in architectural VGPRs (the AGPR half holds the activation fragments,
-# see render_fwd.hip), which removes a v_accvgpr_read per accumulator element from every tile epilogue
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wno-unused-result \
-  -mllvm -amdgpu-mfma-vgpr-form=1 \
-  "$@" -o "$OUT" pack.hip sampler.hip render_fwd.hip
+OBJ=../build_obj
+mkdir -p "$OBJ"
+COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result"
+# -amdgpu-mfma-vgpr-form: MFMA accumulators in architectural VGPRs.  The render / dgrad kernels keep their activation
+# fragments in the AGPR half of the register file (see render_fwd.hip), so this removes a v_accvgpr_read per accumulator
+# element from every tile epilogue.  wgrad.hip holds 256 accumulator registers per lane and wants them in AGPRs.
+for f in pack sampler render_fwd render_bwd; do
+  hipcc $COMMON -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c -o "$OBJ/$f.o" "$f.hip" &
+done
+hipcc $COMMON "$@" -c -o "$OBJ/wgrad.o" wgrad.hip &
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/pack.o "$OBJ"/sampler.o "$OBJ"/render_fwd.o "$OBJ"/render_bwd.o "$OBJ"/wgrad.o
 echo "built $OUT"

@@ -1,0 +1,348 @@
+// Backward pass of the fused emission renderer (gfx950).
+//
+//   loss gradients w.r.t. image (N) and regularization (N,S)
+//     -> integral_bwd_kernel : d/d raw of emission.py:14-54 + base_tracing.py:43-44,108        -> g_raw (N,S,2)
+//     -> dgrad_kernel        : back-propagation through the sine MLP (model.py:44-57), per 32-sample chunk:
+//                              dZ_l = (W_{l+1}^T dZ_{l+1}) * cos(Z_l), written to the dZ stash (fp16 fragments)
+//     -> wgrad (wgrad.hip)   : dW_l = sum_samples dZ_l H_{l-1}^T,  db_l = sum_samples dZ_l
+// No gradient flows to the ray geometry / sample positions (sampling.py:120 detaches the resampled z and the
+// stratified z has no parameters), so layer 0 needs no data gradient.
+//
+// Numerics: the matrix products use single fp16 operands (fp32 accumulate): the reference tolerance for gradients
+// is 1e-3 relative per tensor and the rounding errors (2^-12 relative, unbiased) average out over the samples.  fp16 has
+// a narrow exponent range, so g_raw is multiplied by a power of two `gscale` chosen from max|g_raw| of the batch
+// (computed on the device, no host round trip) and dW / db are multiplied by 1/gscale at the end.
+#include "sunerf_common.h"
+#include "../../include/sunerf_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// integral backward: one thread per ray, sequential over the samples (O(S) flops, HBM-light)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int IB_THREADS = 64;
+
+__global__ __launch_bounds__(IB_THREADS) void integral_bwd_kernel(
+    const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ rays_o,
+    const float* __restrict__ rays_d, const float* __restrict__ g_image, const float* __restrict__ g_reg,
+    float g_reg_const, float reg_radius, int64_t n_rays, int S, float* __restrict__ g_raw,
+    unsigned* __restrict__ g_absmax_bits) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [S][IB_THREADS] emerging intensity I*T
+  const int tid = threadIdx.x;
+  const int64_t ray = (int64_t)blockIdx.x * IB_THREADS + tid;
+  float local_max = 0.f;
+  if (ray < n_rays) {
+    const float ox = rays_o[ray * 3 + 0], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
+    const float dx = rays_d[ray * 3 + 0], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+    const float dnorm = sqrtf((dx * dx + dy * dy) + dz * dz);
+    const float* z = z_vals + ray * S;
+    const float* r = raw + ray * S * 2;
+    float* g = g_raw + ray * S * 2;
+    const float gi = g_image[ray];
+    // forward recomputation: emerging_i = I_i * T_i, T the exclusive product of (a + 1e-10)
+    float T = 1.f;
+    for (int i = 0; i < S; ++i) {
+      const float dzv = (i == 0) ? (z[1] - z[0]) : (z[i] - z[i - 1]);
+      const float dist = dzv * dnorm;
+      const float a = expf(-fmaxf(r[2 * i + 1], 0.f) * dist);
+      lds[i * IB_THREADS + tid] = expf(r[2 * i]) * dist * T;
+      T *= a + 1e-10f;
+    }
+    // reverse sweep: suffix_i = sum_{k>i} emerging_k
+    float suffix = 0.f;
+    for (int i = S - 1; i >= 0; --i) {
+      const float zi = z[i];
+      const float dzv = (i == 0) ? (z[1] - z[0]) : (zi - z[i - 1]);
+      const float dist = dzv * dnorm;
+      const float r1 = r[2 * i + 1];
+      const float a = expf(-fmaxf(r1, 0.f) * dist);
+      const float em = lds[i * IB_THREADS + tid];
+      // image = sum_i em_i :  d/d r0_i = em_i ;  d/d a_i = suffix_i / (a_i + 1e-10)
+      const float g0 = gi * em;
+      float ga = gi * suffix / (a + 1e-10f);
+      // regularization_i = relu(|p_i| - R) (1 - a_i)   (base_tracing.py:43-44, D2 resolved)
+      const float gr = g_reg ? g_reg[ray * S + i] : g_reg_const;
+      if (gr != 0.f) {
+        const float px = ox + dx * zi, py = oy + dy * zi, pz = oz + dz * zi;
+        const float pd = sqrtf((px * px + py * py) + pz * pz);
+        ga -= gr * fmaxf(pd - reg_radius, 0.f);
+      }
+      // a = exp(-relu(r1) dist)
+      const float g1 = (r1 > 0.f) ? ga * (-dist * a) : 0.f;
+      g[2 * i] = g0;
+      g[2 * i + 1] = g1;
+      local_max = fmaxf(local_max, fmaxf(fabsf(g0), fabsf(g1)));
+      suffix += em;
+    }
+  }
+  // max |g_raw| of the batch (bit pattern of a non-negative float orders like an unsigned integer)
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, d));
+  if (tid == 0 && local_max > 0.f && local_max < INFINITY) atomicMax(g_absmax_bits, __float_as_uint(local_max));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dgrad
+// ---------------------------------------------------------------------------------------------------------------
+// Transposed weight image "packedT" (pack_mlp_t_kernel), fp16, consumption order, 1 KiB per k-step (A fragment:
+// lane (m, h) element e = W_l[out feature kmapT][in feature 32U + m]):
+//   [out_layer^T : D/32 tiles x 1 k-step : K slot (h=0,e) = output e of the network (e < d_out), rest zero]
+//   for l = n_linear-2 down to 1: [W_l^T : D/32 tiles x D/16 k-steps, K order = kmap_hidden (fragment order of dZ_l)]
+constexpr int DG_WAVES = 4;
+constexpr int DG_THREADS = DG_WAVES * 64;
+
+struct DgradArgs {
+  const char* packedT;
+  const float* g_raw;          // (N, S, 2)
+  const unsigned* g_absmax_bits;
+  const char* stash;           // activation stash of the forward pass (cos fragments are read)
+  char* dz_stash;              // out: [chunk][n_act layers][KS fragments] fp16 dZ (scaled by gscale)
+  int64_t n_rays;
+  int S;
+  int n_linear;
+};
+
+__device__ __forceinline__ float gscale_from_bits(unsigned bits) {
+  // power of two that brings max|g_raw| to ~2^10 (fp16 max 65504; partial sums over <= 2 outputs stay far below)
+  const float m = __uint_as_float(bits);
+  if (!(m > 0.f)) return 1.f;
+  int e;
+  frexpf(m, &e);                 // m = f * 2^e, f in [0.5, 1)
+  return ldexpf(1.f, 10 - e);
+}
+
+template <int D>
+__global__ __launch_bounds__(DG_THREADS, 1) void dgrad_kernel(DgradArgs a) {
+  constexpr int NT = D / 32, KS = D / 16;
+  constexpr int BLK = KS * 1024;          // one (layer, tile) block of W^T: KS k-steps x 1 KiB
+  constexpr int VEC = BLK / 16 / DG_THREADS;   // 16-byte vectors per thread and block
+  static_assert(BLK % (16 * DG_THREADS) == 0, "block must split evenly over the threads");
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x BLK
+  const StashLayout SL(D, a.n_linear);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, h = lane >> 5;
+  const int n_act = a.n_linear - 1;
+  const int n_chunks = (a.S + 31) >> 5;
+  const int64_t n_groups = (a.n_rays + DG_WAVES - 1) / DG_WAVES;
+  const float gscale = gscale_from_bits(*a.g_absmax_bits);
+  const char* wT_out = a.packedT;                               // NT x 1 KiB
+  const char* wT_hidden = a.packedT + (size_t)NT * 1024;        // (n_linear-2) layers x NT blocks, l descending
+  const size_t dz_chunk_bytes = (size_t)n_act * KS * 1024;
+
+  for (int64_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+    const int64_t ray_raw = group * DG_WAVES + wave;
+    const bool ray_ok = ray_raw < a.n_rays;
+    const int64_t ray = ray_ok ? ray_raw : a.n_rays - 1;
+    for (int c = 0; c < n_chunks; ++c) {
+      const int i = 32 * c + n;
+      const bool valid = ray_ok && i < a.S;
+      // spare chunk for waves without a ray / chunk id of this wave
+      const size_t chunk_id = ray_ok ? (size_t)ray_raw * n_chunks + c : (size_t)a.n_rays * n_chunks;
+      const char* sbase = a.stash + chunk_id * SL.chunk_bytes() + lane * 16;
+      char* dzbase = a.dz_stash + chunk_id * dz_chunk_bytes + lane * 16;
+
+      // dZ of the output layer as a B fragment: K slot 0 / 1 = d loss / d raw[..., 0 / 1]
+      half8 dz_out = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (valid && h == 0) {
+        const f32x2 g = *(const f32x2*)(a.g_raw + ((size_t)ray * a.S + i) * 2);
+        dz_out[0] = (_Float16)(g[0] * gscale);
+        dz_out[1] = (_Float16)(g[1] * gscale);
+      }
+      half8 xa[KS], xb[KS];
+      // ---- out layer: dH_{L-1} = W_out^T dZ_out, one k-step per tile, A fragments straight from L2 ----
+      {
+        const char* cbase = sbase + SL.c_off(n_act - 1);
+        char* dzl = dzbase + (size_t)(n_act - 1) * KS * 1024;
+#pragma unroll
+        for (int U = 0; U < NT; ++U) {
+          const half8 aT = *(const half8*)(wT_out + U * 1024 + lane * 16);
+          f32x16 acc = {0};
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aT, dz_out, acc, 0, 0, 0);
+          const half8 c0 = *(const half8*)(cbase + (2 * U) * 1024), c1 = *(const half8*)(cbase + (2 * U + 1) * 1024);
+          half8 d0, d1;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { d0[j] = (_Float16)(acc[j] * (float)c0[j]); d1[j] = (_Float16)(acc[8 + j] * (float)c1[j]); }
+          xa[2 * U] = d0; xa[2 * U + 1] = d1;
+          *(half8*)(dzl + (2 * U) * 1024) = d0;
+          *(half8*)(dzl + (2 * U + 1) * 1024) = d1;
+        }
+      }
+      // ---- hidden layers, l = n_linear-2 ... 1 : dZ_{l-1} = (W_l^T dZ_l) * cos(Z_{l-1}) ----
+      // blocks are staged global -> registers -> LDS (double buffer) one block ahead by all 256 threads
+      const int n_hidden = a.n_linear - 2;
+      const int n_blocks = n_hidden * NT;
+      f32x4 stage[VEC];
+      if (n_blocks > 0) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) stage[v] = *(const f32x4*)(wT_hidden + (size_t)(v * DG_THREADS + tid) * 16);
+        __syncthreads();   // previous chunk's readers of buffer 0 are done
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) *(f32x4*)(smem + (size_t)(v * DG_THREADS + tid) * 16) = stage[v];
+        __syncthreads();
+      }
+      int blk = 0;
+      auto hidden_layer = [&](int l, const half8* x, half8* y) {   // consumes dZ_l (x), produces dZ_{l-1} (y)
+        const char* cbase = sbase + SL.c_off(l - 1);
+        char* dzl = dzbase + (size_t)(l - 1) * KS * 1024;
+#pragma unroll
+        for (int U = 0; U < NT; ++U) {
+          const char* buf = smem + (blk & 1) * BLK;
+          const bool more = blk + 1 < n_blocks;
+          if (more) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+              stage[v] = *(const f32x4*)(wT_hidden + (size_t)(blk + 1) * BLK + (size_t)(v * DG_THREADS + tid) * 16);
+          }
+          const half8 c0 = *(const half8*)(cbase + (2 * U) * 1024), c1 = *(const half8*)(cbase + (2 * U + 1) * 1024);
+          f32x16 acc = {0};
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            const half8 aT = *(const half8*)(buf + s * 1024 + lane * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aT, x[s], acc, 0, 0, 0);
+          }
+          half8 d0, d1;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { d0[j] = (_Float16)(acc[j] * (float)c0[j]); d1[j] = (_Float16)(acc[8 + j] * (float)c1[j]); }
+          y[2 * U] = d0; y[2 * U + 1] = d1;
+          *(half8*)(dzl + (2 * U) * 1024) = d0;
+          *(half8*)(dzl + (2 * U + 1) * 1024) = d1;
+          if (more) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) *(f32x4*)(smem + ((blk + 1) & 1) * BLK + (size_t)(v * DG_THREADS + tid) * 16) = stage[v];
+          }
+          __syncthreads();
+          ++blk;
+        }
+      };
+      int l = a.n_linear - 2;
+      for (; l - 1 >= 1; l -= 2) {
+        hidden_layer(l, xa, xb);
+        hidden_layer(l - 1, xb, xa);
+      }
+      if (l >= 1) hidden_layer(l, xa, xb);
+    }
+  }
+}
+
+// ---- packing of the transposed image ------------------------------------------------------------------------
+struct PackTArgs {
+  const float* W[SUNERF_MAX_LAYERS];
+  int n_linear, D, d_out;
+  char* packedT;
+};
+
+__global__ void pack_mlp_t_kernel(PackTArgs a) {
+  const int NT = a.D / 32, KS = a.D / 16;
+  const size_t n_out = (size_t)NT * 512;                               // halfs of the out^T part
+  const size_t n_hid = (size_t)(a.n_linear - 2) * NT * KS * 512;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_out + n_hid) return;
+  _Float16* dst = (_Float16*)a.packedT;
+  float w = 0.f;
+  if (idx < n_out) {
+    const int U = (int)(idx / 512), lane = (int)(idx % 512) / 8, e = (int)(idx % 8);
+    const int m = lane & 31, h = lane >> 5;
+    if (h == 0 && e < a.d_out) w = a.W[a.n_linear - 1][(size_t)e * a.D + 32 * U + m];
+  } else {
+    size_t r = idx - n_out;
+    const int li = (int)(r / ((size_t)NT * KS * 512));   // 0 -> layer n_linear-2, 1 -> n_linear-3, ...
+    r %= (size_t)NT * KS * 512;
+    const int l = a.n_linear - 2 - li;
+    const int U = (int)(r / ((size_t)KS * 512)); r %= (size_t)KS * 512;
+    const int s = (int)(r / 512); r %= 512;
+    const int lane = (int)(r / 8), e = (int)(r % 8);
+    const int m = lane & 31, h = lane >> 5;
+    // A[m][k] = W_l^T[in = 32U+m][out = kmap_hidden(s,h,e)] = W_l[out][in]
+    w = a.W[l][(size_t)kmap_hidden(s, h, e) * a.D + 32 * U + m];
+  }
+  dst[idx] = (_Float16)w;
+}
+
+}  // namespace
+
+extern "C" size_t sunerf_packed_mlp_t_bytes(int d_filter, int n_linear) {
+  if (d_filter <= 0 || d_filter % 32 || n_linear < 2 || n_linear > SUNERF_MAX_LAYERS) return 0;
+  const size_t NT = d_filter / 32, KS = d_filter / 16;
+  return NT * 1024 + (size_t)(n_linear - 2) * NT * KS * 1024;
+}
+
+extern "C" int sunerf_pack_mlp_t(const float* const* weights_host, int n_linear, int d_filter, int d_out, void* packedT,
+                                 void* stream) {
+  if (!weights_host || !packedT) return SUNERF_E_BADARG;
+  if (d_filter <= 0 || d_filter % 32 || n_linear < 2 || n_linear > SUNERF_MAX_LAYERS || d_out < 1 || d_out > 8)
+    return SUNERF_E_UNSUPPORTED;
+  PackTArgs a;
+  for (int i = 0; i < n_linear; ++i) {
+    if (!weights_host[i]) return SUNERF_E_BADARG;
+    a.W[i] = weights_host[i];
+  }
+  a.n_linear = n_linear; a.D = d_filter; a.d_out = d_out; a.packedT = (char*)packedT;
+  const size_t total = sunerf_packed_mlp_t_bytes(d_filter, n_linear) / 2;
+  const int threads = 256;
+  SUNERF_CLEAR_ERROR();
+  hipLaunchKernelGGL(pack_mlp_t_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0,
+                     (hipStream_t)stream, a);
+  SUNERF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t sunerf_dz_stash_bytes(int64_t n_rays, int n_samples, int d_filter, int n_linear) {
+  if (n_rays < 0 || n_samples < 1 || d_filter < 32 || d_filter % 32 || n_linear < 2) return 0;
+  const int64_t chunks = n_rays * ((n_samples + 31) / 32) + 1;
+  return (size_t)chunks * (size_t)(n_linear - 1) * (d_filter / 16) * 1024;
+}
+
+extern "C" int sunerf_emission_integral_bwd(const float* raw, const float* z_vals, const float* rays_o, const float* rays_d,
+                                            const float* g_image, const float* g_reg, float g_reg_const, float reg_radius,
+                                            int64_t n_rays, int n_samples, float* g_raw, void* g_absmax, void* stream) {
+  if (!raw || !z_vals || !rays_o || !rays_d || !g_image || !g_raw || !g_absmax) return SUNERF_E_BADARG;
+  if (n_rays < 0 || n_samples < 2) return SUNERF_E_BADARG;
+  const size_t lds = (size_t)n_samples * IB_THREADS * sizeof(float);
+  if (lds > 160 * 1024) return SUNERF_E_UNSUPPORTED;
+  hipError_t e = hipMemsetAsync(g_absmax, 0, 4, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  if (n_rays == 0) return 0;
+  if (lds > 64 * 1024) {
+    e = hipFuncSetAttribute((const void*)integral_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int64_t blocks = (n_rays + IB_THREADS - 1) / IB_THREADS;
+  SUNERF_CLEAR_ERROR();
+  hipLaunchKernelGGL(integral_bwd_kernel, dim3((unsigned)blocks), dim3(IB_THREADS), lds, (hipStream_t)stream, raw, z_vals,
+                     rays_o, rays_d, g_image, g_reg, g_reg_const, reg_radius, n_rays, n_samples, g_raw, (unsigned*)g_absmax);
+  SUNERF_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int D>
+static int launch_dgrad(const DgradArgs& a, hipStream_t stream) {
+  const size_t lds = 2 * (size_t)(D / 16) * 1024;
+  hipError_t e = hipFuncSetAttribute((const void*)dgrad_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  const int64_t n_groups = (a.n_rays + DG_WAVES - 1) / DG_WAVES;
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const unsigned grid = (unsigned)(n_groups < cus ? n_groups : cus);
+  SUNERF_CLEAR_ERROR();
+  hipLaunchKernelGGL(dgrad_kernel<D>, dim3(grid), dim3(DG_THREADS), lds, stream, a);
+  SUNERF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sunerf_mlp_dgrad(const void* packedT, int d_filter, int n_linear, const float* g_raw, const void* g_absmax,
+                                const void* act_stash, void* dz_stash, int64_t n_rays, int n_samples, void* stream) {
+  if (!packedT || !g_raw || !g_absmax || !act_stash || !dz_stash) return SUNERF_E_BADARG;
+  if (n_rays < 0 || n_samples < 2) return SUNERF_E_BADARG;
+  if (n_linear < 2 || n_linear > SUNERF_MAX_LAYERS) return SUNERF_E_UNSUPPORTED;
+  if (n_rays == 0) return 0;
+  DgradArgs a;
+  a.packedT = (const char*)packedT; a.g_raw = g_raw; a.g_absmax_bits = (const unsigned*)g_absmax;
+  a.stash = (const char*)act_stash; a.dz_stash = (char*)dz_stash; a.n_rays = n_rays; a.S = n_samples; a.n_linear = n_linear;
+  switch (d_filter) {
+    case 64: return launch_dgrad<64>(a, (hipStream_t)stream);
+    case 128: return launch_dgrad<128>(a, (hipStream_t)stream);
+    case 256: return launch_dgrad<256>(a, (hipStream_t)stream);
+    default: return SUNERF_E_UNSUPPORTED;
+  }
+}

@@ -138,14 +138,12 @@ struct Ring {
   template <int J>
   __device__ __forceinline__ void issue_piece() {
     static_assert(J >= 0 && J < PIECES, "piece index");
-#ifndef SUNERF_ABL_NODMA
     {
       const char* sg = src + (J / 4) * 4096;
       const unsigned dg = dst + (J / 4) * 4096;
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 offset:%3"
                    :: "v"(voff), "s"(dg), "s"(sg), "i"((J % 4) * 1024) : "memory");
     }
-#endif
     if (J == PIECES - 1) {   // page complete: advance to the next page / ring slot
       src += PAGE;
       if (src == src_end) src = src_first;
@@ -160,11 +158,12 @@ struct Ring {
   }
   // makes the next page readable: this wave's pieces of it have landed (the PIECES younger ones, of the page after
   // it, may still be in flight), then everyone's
+  // EXTRA = vector-memory operations (stash stores) that are guaranteed to have been issued after the last piece of
+  // the page being acquired, besides the PIECES of the following page
+  template <int EXTRA = 0>
   __device__ __forceinline__ void acquire() {
-    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PIECES) : "memory");
-#ifndef SUNERF_ABL_NOBARRIER
+    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PIECES + EXTRA) : "memory");
     __builtin_amdgcn_s_barrier();
-#endif
   }
 };
 
@@ -177,20 +176,27 @@ __device__ __forceinline__ void pin_agpr(half8& f) { asm volatile("" : "+a"(f));
 
 // Epilogue of one accumulator tile = 8 "pair" micro-ops (elements 2p, 2p+1 -> one dword of a hi and of a lo fragment),
 // each cut into three stages that are issued behind the three MFMAs of a k-step of the NEXT tile:
-//   A: sin (argument in revolutions: the 1/(2 pi) is folded into the packed weights)
+//   A: sin (argument in revolutions: the 1/(2 pi) is folded into the packed weights) [training: and cos]
 //   B: hi = fp16(x) (packed), remainder x - hi
-//   C: lo = fp16(remainder) (packed), insert into the fragments
+//   C: lo = fp16(remainder) (packed), insert into the fragments [training: stash fp16(sin), fp16(cos) fragments]
 // The empty asm statements anchor every stage where it is written: without them the optimiser sinks the whole
 // epilogue to its only consumer (the end of the tile), where it would run unoverlapped with matrix work.
 struct PairTmp {
-  float s0, s1, r0, r1;
-  half2v hi;
+  float s0, s1, r0, r1, c0, c1;
+  half2v hi, cpk;
 };
+template <bool STASH>
 __device__ __forceinline__ void epi_stage_a(const f32x16& acc, int p, PairTmp& t) {
   t.s0 = __builtin_amdgcn_sinf(acc[2 * p]);
   t.s1 = __builtin_amdgcn_sinf(acc[2 * p + 1]);
   asm volatile("" : "+v"(t.s0), "+v"(t.s1));
+  if (STASH) {   // d sin(z)/dz for the backward pass
+    t.c0 = __builtin_amdgcn_cosf(acc[2 * p]);
+    t.c1 = __builtin_amdgcn_cosf(acc[2 * p + 1]);
+    asm volatile("" : "+v"(t.c0), "+v"(t.c1));
+  }
 }
+template <bool STASH>
 __device__ __forceinline__ void epi_stage_b(PairTmp& t) {
   const f32x2 sv = {t.s0, t.s1};
   t.hi = __builtin_convertvector(sv, half2v);   // one v_cvt_pk_f16_f32 (round to nearest even)
@@ -198,15 +204,34 @@ __device__ __forceinline__ void epi_stage_b(PairTmp& t) {
   t.r0 = t.s0 - (float)t.hi[0];
   t.r1 = t.s1 - (float)t.hi[1];
   asm volatile("" : "+v"(t.hi), "+v"(t.r0), "+v"(t.r1));
+  if (STASH) {
+    const f32x2 cv = {t.c0, t.c1};
+    t.cpk = __builtin_convertvector(cv, half2v);
+    asm volatile("" : "+v"(t.cpk));
+  }
 }
-__device__ __forceinline__ void epi_stage_c(const PairTmp& t, int p, half8& hi0, half8& lo0, half8& hi1, half8& lo1) {
+// `st`: this lane's address of the tile's first H fragment in the stash (training only); `cos_delta` = byte distance
+// from an H fragment to the matching cos fragment
+template <bool STASH>
+__device__ __forceinline__ void epi_stage_c(const PairTmp& t, int p, half8& hi0, half8& lo0, half8& hi1, half8& lo1,
+                                            half8& ch0, half8& ch1, char* st, int cos_delta) {
   half2v lo;
   lo[0] = (_Float16)t.r0; lo[1] = (_Float16)t.r1;
   if (p < 4) { hi0[2 * p] = t.hi[0]; hi0[2 * p + 1] = t.hi[1]; lo0[2 * p] = lo[0]; lo0[2 * p + 1] = lo[1]; }
   else { hi1[2 * p - 8] = t.hi[0]; hi1[2 * p - 7] = t.hi[1]; lo1[2 * p - 8] = lo[0]; lo1[2 * p - 7] = lo[1]; }
+  if (STASH) {
+    if (p < 4) { ch0[2 * p] = t.cpk[0]; ch0[2 * p + 1] = t.cpk[1]; }
+    else { ch1[2 * p - 8] = t.cpk[0]; ch1[2 * p - 7] = t.cpk[1]; }
+  }
   // (pinning after every insertion instead makes hipcc rewrite the whole 4-dword tuple each time: measured worse)
-  if (p == 3) { pin_agpr(hi0); pin_agpr(lo0); }
-  if (p == 7) { pin_agpr(hi1); pin_agpr(lo1); }
+  if (p == 3) {
+    pin_agpr(hi0); pin_agpr(lo0);
+    if (STASH) { *(half8*)st = hi0; *(half8*)(st + cos_delta) = ch0; }
+  }
+  if (p == 7) {
+    pin_agpr(hi1); pin_agpr(lo1);
+    if (STASH) { *(half8*)(st + 1024) = hi1; *(half8*)(st + 1024 + cos_delta) = ch1; }
+  }
 }
 
 __device__ __forceinline__ f32x16 bias_tile(const float* bias, int h) {
@@ -288,63 +313,58 @@ struct Mlp {
   // k-steps of one tile.  T0 = stream position (in k-steps) of the tile's first k-step relative to a page boundary
   // (tiles of the in layer are 6 k-steps and straddle pages; all other tiles start on a page boundary).
   // `prev`: accumulator of the previous tile whose epilogue is interleaved here (HAS_PREV), writing y*.
-  template <int KIN, int T0, bool HAS_PREV, int RS0>
+  // STASH (training): the epilogue also stores fp16 sin / cos fragments at `st` (4 stores of 1 KiB per tile); in a
+  // steady-state page cycle those 4 stores are younger than the page being acquired, hence acquire<4>.
+  template <int KIN, int T0, bool HAS_PREV, int RS0, bool STASH>
   static __device__ __forceinline__ f32x16 tile(Ring<D>& ring, Pipe& p, f32x16 acc, const half8* xhi, const half8* xlo,
-                                                const f32x16& prev, half8& yh0, half8& yl0, half8& yh1, half8& yl1) {
+                                                const f32x16& prev, half8& yh0, half8& yl0, half8& yh1, half8& yl1,
+                                                char* st, int cos_delta) {
     // k-steps that carry epilogue micro-ops.  For the first tile of a layer the epilogue produces the layer's own last
     // two input fragments (read by k-steps KIN-2 and KIN-1), so it must be complete before k-step KIN-2.
     constexpr int EPI_STEPS = (KIN - 2) >= 8 ? 8 : (KIN - 2);
     static_assert(EPI_STEPS >= 1, "tile too short to hide the previous tile's epilogue");
     constexpr int PER = (8 + EPI_STEPS - 1) / EPI_STEPS;   // pair micro-ops per k-step
+    constexpr int ACQ = (PAGE_STEPS - PF) % PAGE_STEPS;    // page phase at which the next page is acquired
+    half8 ch0, ch1;                                        // fp16 cos fragments (training)
 #pragma unroll
     for (int s = 0; s < KIN; ++s) {
       const int r = (T0 + s) % PF;
       PairTmp t[PER];
       // --- MFMA 1 | stage A --------------------------------------------------------------------------------
       acc = mfma16(p.alo[r], xhi[s], acc);
-#ifndef SUNERF_ABL_NOEPI
       if (HAS_PREV) {
 #pragma unroll
         for (int q = 0; q < PER; ++q)
-          if (s * PER + q < 8) epi_stage_a(prev, s * PER + q, t[q]);
+          if (s * PER + q < 8) epi_stage_a<STASH>(prev, s * PER + q, t[q]);
       }
-#else
-      if (HAS_PREV && s == 0) asm volatile("" :: "v"(prev));   // ablation: keep the MFMA chain alive
-#endif
       __builtin_amdgcn_sched_barrier(0);
       // --- MFMA 2 | stage B --------------------------------------------------------------------------------
       acc = mfma16(p.ahi[r], xlo[s], acc);
-#ifndef SUNERF_ABL_NOEPI
       if (HAS_PREV) {
 #pragma unroll
         for (int q = 0; q < PER; ++q)
-          if (s * PER + q < 8) epi_stage_b(t[q]);
+          if (s * PER + q < 8) epi_stage_b<STASH>(t[q]);
       }
-#endif
       __builtin_amdgcn_sched_barrier(0);
       // --- MFMA 3 | stage C | next page | A-fragment reads of k-step s + PF --------------------------------------
       acc = mfma16(p.ahi[r], xhi[s], acc);
-#ifndef SUNERF_ABL_NOEPI
       if (HAS_PREV) {
 #pragma unroll
         for (int q = 0; q < PER; ++q)
-          if (s * PER + q < 8) epi_stage_c(t[q], s * PER + q, yh0, yl0, yh1, yl1);
+          if (s * PER + q < 8) epi_stage_c<STASH>(t[q], s * PER + q, yh0, yl0, yh1, yl1, ch0, ch1, st, cos_delta);
       }
-#endif
       {
-        constexpr int ACQ = (PAGE_STEPS - PF) % PAGE_STEPS;          // page phase at which the next page is acquired
         const int phase = (T0 + s) % PAGE_STEPS;
-        if (phase == ACQ) ring.acquire();                            // the reads below cross into the next page
+        if (phase == ACQ) {                                          // the reads below cross into the next page
+          if (STASH && HAS_PREV && KIN == KS) ring.template acquire<4>();
+          else ring.template acquire<0>();
+        }
         const int rel = (phase - ACQ - 1 + PAGE_STEPS) % PAGE_STEPS; // k-steps since the acquire, minus one
         if (rel % 2 == 0 && rel / 2 < Ring<D>::PIECES) issue_piece_dyn(ring, rel / 2);
       }
-#ifdef SUNERF_ABL_NOLDS
-      if (false) {
-#else
       if (RS0 >= 0) {
-#endif
         load_frag(p, r, (RS0 + s + PF) % RING_STEPS);
-      } else if (RS0 < 0) {
+      } else {
         int rs = p.rstep + s + PF;
         rs = rs >= RING_STEPS ? rs - RING_STEPS : rs;
         load_frag(p, r, rs);
@@ -361,19 +381,21 @@ struct Mlp {
   // one layer: X (KIN k-steps) -> Y (KS k-steps).  `carry` is the accumulator of the previous layer's last tile,
   // whose epilogue (into that layer's output set = our X, fragments 2*NT-2, 2*NT-1) overlaps our first tile: those
   // fragments are only read by our last two k-steps.  Returns our own last accumulator the same way.
-  template <int KIN, bool HAS_CARRY, int RSL0>
+  // st_prev / st_own: this lane's stash address of fragment 0 of the previous / of this layer's H block (training).
+  template <int KIN, bool HAS_CARRY, int RSL0, bool STASH>
   static __device__ __forceinline__ f32x16 layer(Ring<D>& ring, Pipe& p, const float* bias, int h, half8* xhi, half8* xlo,
-                                                 half8* yhi, half8* ylo, const f32x16& carry) {
+                                                 half8* yhi, half8* ylo, const f32x16& carry, char* st_prev, char* st_own) {
     f32x16 prev = carry;
+    constexpr int CD = KS * 1024;
 #pragma unroll
     for (int U = 0; U < NT; ++U) {
       f32x16 acc = bias_tile(bias + 32 * U, h);
       constexpr int XL = 2 * NT - 2;   // previous layer's last tile -> our X fragments
-#define SUNERF_TILE(UU)                                                                                        \
-      if (U == UU) {                                                                                             \
-        constexpr int RS = RSL0 < 0 ? -1 : (RSL0 + UU * KIN) % RING_STEPS;                                       \
-        if (UU == 0) acc = tile<KIN, (UU * KIN) % KS, HAS_CARRY, RS>(ring, p, acc, xhi, xlo, prev, xhi[XL], xlo[XL], xhi[XL + 1], xlo[XL + 1]); \
-        else acc = tile<KIN, (UU * KIN) % KS, true, RS>(ring, p, acc, xhi, xlo, prev, yhi[2 * UU - 2], ylo[2 * UU - 2], yhi[2 * UU - 1], ylo[2 * UU - 1]); \
+#define SUNERF_TILE(UU)                                                                                          \
+      if (U == UU) {                                                                                               \
+        constexpr int RS = RSL0 < 0 ? -1 : (RSL0 + UU * KIN) % RING_STEPS;                                         \
+        if (UU == 0) acc = tile<KIN, (UU * KIN) % KS, HAS_CARRY, RS, STASH>(ring, p, acc, xhi, xlo, prev, xhi[XL], xlo[XL], xhi[XL + 1], xlo[XL + 1], st_prev + XL * 1024, CD); \
+        else acc = tile<KIN, (UU * KIN) % KS, true, RS, STASH>(ring, p, acc, xhi, xlo, prev, yhi[2 * UU - 2], ylo[2 * UU - 2], yhi[2 * UU - 1], ylo[2 * UU - 1], st_own + (2 * UU - 2) * 1024, CD); \
       }
       SUNERF_TILE(0) SUNERF_TILE(1) SUNERF_TILE(2) SUNERF_TILE(3) SUNERF_TILE(4) SUNERF_TILE(5) SUNERF_TILE(6) SUNERF_TILE(7)
 #undef SUNERF_TILE
@@ -382,18 +404,21 @@ struct Mlp {
     return prev;
   }
 
+  template <bool STASH>
   static __device__ __forceinline__ f32x16 out_layer(Ring<D>& ring, Pipe& p, const float* bias, int h, half8* xhi,
-                                                     half8* xlo, const f32x16& carry) {
+                                                     half8* xlo, const f32x16& carry, char* st_prev) {
     constexpr int XL = 2 * NT - 2;
-    return tile<KS, 0, true, RS_HIDDEN>(ring, p, bias_tile(bias, h), xhi, xlo, carry, xhi[XL], xlo[XL], xhi[XL + 1], xlo[XL + 1]);
+    return tile<KS, 0, true, RS_HIDDEN, STASH>(ring, p, bias_tile(bias, h), xhi, xlo, carry, xhi[XL], xlo[XL], xhi[XL + 1],
+                                               xlo[XL + 1], st_prev + XL * 1024, KS * 1024);
   }
 };
 
-template <int D>
+template <int D, bool STASH>
 __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
   using M = Mlp<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const PackedLayout L(D, a.n_linear);
+  const StashLayout SL(D, a.n_linear);
   char* slot = smem;                                            // ring of NSLOT weight pages
   float* bias = (float*)(smem + (size_t)Ring<D>::RING);          // n_bias floats
   const int tid = threadIdx.x;
@@ -446,22 +471,37 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
 #pragma unroll
         for (int s = 0; s < SUNERF_KS0; ++s) { pin_agpr(xb_hi[s]); pin_agpr(xb_lo[s]); }
       }
+      // training: this chunk's slice of the activation stash (lane-adjusted); enc fragments first
+      char* sbase = nullptr;
+      if (STASH) {
+        // waves of a ragged last group (no ray) run the same instruction stream: they write to one spare chunk
+        const size_t chunk_id = ray_ok ? (size_t)ray_raw * n_chunks + c : (size_t)a.n_rays * n_chunks;
+        sbase = a.stash + chunk_id * SL.chunk_bytes() + lane * 16;
+      }
+      if (STASH) {
+#pragma unroll
+        for (int s = 0; s < SUNERF_KS0; ++s) *(half8*)(sbase + s * 1024) = xb_hi[s];
+      }
       // in layer: 84(96) -> D
       f32x16 carry = {0};
-      carry = M::template layer<SUNERF_KS0, false, M::RS_IN>(ring, pipe, bias, h, xb_hi, xb_lo, xa_hi, xa_lo, carry);
+      carry = M::template layer<SUNERF_KS0, false, M::RS_IN, STASH>(ring, pipe, bias, h, xb_hi, xb_lo, xa_hi, xa_lo, carry,
+                                                                    nullptr, sbase + SL.h_off(0));
       // hidden layers, ping-pong between the two register sets
       int l = 1;
       for (; l + 1 < a.n_linear - 1; l += 2) {
-        carry = M::template layer<M::KS, true, M::RS_HIDDEN>(ring, pipe, bias + (size_t)l * D, h, xa_hi, xa_lo, xb_hi, xb_lo, carry);
-        carry = M::template layer<M::KS, true, M::RS_HIDDEN>(ring, pipe, bias + (size_t)(l + 1) * D, h, xb_hi, xb_lo, xa_hi, xa_lo, carry);
+        carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)l * D, h, xa_hi, xa_lo, xb_hi, xb_lo,
+                                                                    carry, sbase + SL.h_off(l - 1), sbase + SL.h_off(l));
+        carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)(l + 1) * D, h, xb_hi, xb_lo, xa_hi,
+                                                                    xa_lo, carry, sbase + SL.h_off(l), sbase + SL.h_off(l + 1));
       }
       f32x16 out;
       const float* obias = bias + (size_t)(a.n_linear - 1) * D;
       if (l < a.n_linear - 1) {
-        carry = M::template layer<M::KS, true, M::RS_HIDDEN>(ring, pipe, bias + (size_t)l * D, h, xa_hi, xa_lo, xb_hi, xb_lo, carry);
-        out = M::out_layer(ring, pipe, obias, h, xb_hi, xb_lo, carry);
+        carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)l * D, h, xa_hi, xa_lo, xb_hi, xb_lo,
+                                                                    carry, sbase + SL.h_off(l - 1), sbase + SL.h_off(l));
+        out = M::template out_layer<STASH>(ring, pipe, obias, h, xb_hi, xb_lo, carry, sbase + SL.h_off(l));
       } else {
-        out = M::out_layer(ring, pipe, obias, h, xa_hi, xa_lo, carry);
+        out = M::template out_layer<STASH>(ring, pipe, obias, h, xa_hi, xa_lo, carry, sbase + SL.h_off(l - 1));
       }
 
       // ---- emission / absorption integral for this chunk (emission.py:14-54); lanes 0..31 hold rows 0,1 ----
@@ -521,12 +561,12 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two prefetches still in flight target our LDS: drain
 }
 
-template <int D>
-int launch_render(const RenderArgs& a, hipStream_t stream) {
+template <int D, bool STASH>
+int launch_render_t(const RenderArgs& a, hipStream_t stream) {
   const PackedLayout L(D, a.n_linear);
   const size_t lds = (size_t)Ring<D>::RING + L.n_bias() * 4;
   if (lds > 160 * 1024) return SUNERF_E_UNSUPPORTED;
-  hipError_t e = hipFuncSetAttribute((const void*)render_fwd_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute((const void*)render_fwd_kernel<D, STASH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   const int64_t n_groups = (a.n_rays + WAVES - 1) / WAVES;
   int dev = 0, cus = 256;
@@ -534,17 +574,21 @@ int launch_render(const RenderArgs& a, hipStream_t stream) {
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const unsigned grid = (unsigned)(n_groups < cus ? n_groups : cus);
   SUNERF_CLEAR_ERROR();
-  hipLaunchKernelGGL(render_fwd_kernel<D>, dim3(grid), dim3(THREADS), lds, stream, a);
+  hipLaunchKernelGGL((render_fwd_kernel<D, STASH>), dim3(grid), dim3(THREADS), lds, stream, a);
   SUNERF_CHECK_LAUNCH();
   return 0;
+}
+template <int D>
+int launch_render(const RenderArgs& a, hipStream_t stream) {
+  return a.stash ? launch_render_t<D, true>(a, stream) : launch_render_t<D, false>(a, stream);
 }
 
 }  // namespace
 
 extern "C" size_t sunerf_act_stash_bytes(int64_t n_rays, int n_samples, int d_filter, int n_linear) {
-  if (n_rays < 0 || n_samples < 1 || d_filter < 32 || n_linear < 2) return 0;
-  const int64_t chunks = n_rays * ((n_samples + 31) / 32);
-  return (size_t)chunks * (size_t)(n_linear - 1) * d_filter * 32 * 4;
+  if (n_rays < 0 || n_samples < 1 || d_filter < 32 || d_filter % 32 || n_linear < 2) return 0;
+  const int64_t chunks = n_rays * ((n_samples + 31) / 32) + 1;   // + one spare chunk for ragged groups
+  return (size_t)chunks * StashLayout(d_filter, n_linear).chunk_bytes();
 }
 
 extern "C" int sunerf_emission_render_fwd(const void* packed, int d_filter, int n_linear, const float* rays_o,

@@ -67,6 +67,20 @@ struct PackedLayout {
   __host__ __device__ size_t total_bytes() const { return bias_off() + n_bias() * 4; }
 };
 
+// Activation stash written by the training forward pass and read by the backward kernels.  Everything is kept in
+// MFMA B-fragment order (1 KiB per fragment: lane l = 16 bytes = 8 fp16 at offset 16 l; element e of lane half h of
+// fragment s is feature kmap_hidden(s, h, e) of sample l & 31), i.e. exactly the registers the forward kernel holds,
+// so a fragment is one fully coalesced 1 KiB store.  Per 32-sample chunk:
+//   [enc : 6 fragments, fp16(hi) of the encoded input (kmap_encoding order)]
+//   for every activation layer l = 0 .. n_linear-2:  [H_l : D/16 fragments, fp16(sin)] [C_l : D/16 fragments, fp16(cos)]
+struct StashLayout {
+  int KS, n_act;
+  __host__ __device__ StashLayout(int d, int n_linear) : KS(d / 16), n_act(n_linear - 1) {}
+  __host__ __device__ size_t chunk_bytes() const { return ((size_t)SUNERF_KS0 + (size_t)n_act * 2 * KS) * 1024; }
+  __host__ __device__ size_t h_off(int l) const { return ((size_t)SUNERF_KS0 + (size_t)l * 2 * KS) * 1024; }
+  __host__ __device__ size_t c_off(int l) const { return h_off(l) + (size_t)KS * 1024; }
+};
+
 // input feature (column of the nn.Linear weight) held by (k-step s, lane half h, element e); -1 = zero pad
 __host__ __device__ inline int kmap_hidden(int s, int h, int e) {
   return 32 * (s >> 1) + 16 * (s & 1) + 8 * (e >> 2) + 4 * h + (e & 3);

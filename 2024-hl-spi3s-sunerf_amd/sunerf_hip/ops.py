@@ -54,6 +54,8 @@ class PackedMLP:
             raise ValueError(f'unsupported MLP shape: d_filter={self.d_filter}, n_linear={self.n_linear}')
         self.device = weights[0].device
         self.buffer = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.buffer_t = None        # transposed image for the backward pass, packed on demand
+        self._t_valid = False
         self.repack(weights, biases)
 
     def repack(self, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]):
@@ -71,6 +73,22 @@ class PackedMLP:
                                  _stream(self.device))
         _l.check(st, 'sunerf_pack_mlp')
         self._keepalive = (ws, bs)   # until the pack kernel has run on the stream
+        self._t_valid = False
+
+    def transposed(self) -> torch.Tensor:
+        """fp16 W^T image consumed by sunerf_mlp_dgrad (packed lazily, once per parameter version)."""
+        lib = _l.load()
+        if self.buffer_t is None:
+            self.buffer_t = torch.empty(lib.sunerf_packed_mlp_t_bytes(self.d_filter, self.n_linear), dtype=torch.uint8,
+                                        device=self.device)
+        if not self._t_valid:
+            ws = self._keepalive[0]
+            W = (ctypes.c_void_p * self.n_linear)(*[w.data_ptr() for w in ws])
+            st = lib.sunerf_pack_mlp_t(W, self.n_linear, self.d_filter, self.d_out, _ptr(self.buffer_t),
+                                       _stream(self.device))
+            _l.check(st, 'sunerf_pack_mlp_t')
+            self._t_valid = True
+        return self.buffer_t
 
 
 def sample_z(kind: int, rays_o, rays_d, t_vals, distance: float, solar_R: float,
@@ -91,9 +109,10 @@ def sample_z(kind: int, rays_o, rays_d, t_vals, distance: float, solar_R: float,
 
 
 def emission_render_fwd(packed: PackedMLP, rays_o, rays_d, times, z_vals, reg_radius: float,
-                        want_raw: bool = False, want_epilogues: bool = False):
+                        want_raw: bool = False, want_epilogues: bool = False, training: bool = False):
     """One fused render pass.  Returns dict(image (N,1), weights (N,S), absorption (N,S)[, raw (N,S,2)]
-    [, height_map (N,), absorption_map (N,), regularization (N,S)])."""
+    [, height_map (N,), absorption_map (N,), regularization (N,S)][, stash]).  ``training=True`` also writes the
+    activation stash needed by :func:`emission_render_bwd` (and implies ``want_raw``)."""
     lib = _l.load()
     n, s = z_vals.shape
     dev = z_vals.device
@@ -106,17 +125,24 @@ def emission_render_fwd(packed: PackedMLP, rays_o, rays_d, times, z_vals, reg_ra
     f32 = dict(dtype=torch.float32, device=dev)
     out = {'image': torch.empty(n, 1, **f32), 'weights': torch.empty(n, s, **f32),
            'absorption': torch.empty(n, s, **f32)}
+    want_raw = want_raw or training
     raw = torch.empty(n, s, 2, **f32) if want_raw else None
+    stash = None
+    if training:
+        stash = torch.empty(lib.sunerf_act_stash_bytes(n, s, packed.d_filter, packed.n_linear), dtype=torch.uint8,
+                            device=dev)
     hm = am = reg = None
     if want_epilogues:
         hm, am, reg = torch.empty(n, **f32), torch.empty(n, **f32), torch.empty(n, s, **f32)
     st = lib.sunerf_emission_render_fwd(_ptr(packed.buffer), packed.d_filter, packed.n_linear, _ptr(rays_o),
                                         _ptr(rays_d), _ptr(times), _ptr(z_vals), n, s, _ptr(out['image']),
                                         _ptr(out['weights']), _ptr(out['absorption']), _ptr(raw), _ptr(hm), _ptr(am),
-                                        _ptr(reg), float(reg_radius), None, _stream(dev))
+                                        _ptr(reg), float(reg_radius), _ptr(stash), _stream(dev))
     _l.check(st, 'sunerf_emission_render_fwd')
     if want_raw:
         out['raw'] = raw
+    if training:
+        out['stash'] = stash
     if want_epilogues:
         out.update(height_map=hm, absorption_map=am, regularization=reg)
     return out
@@ -137,3 +163,47 @@ def hier_resample(z_vals, weights, u: torch.Tensor) -> Tuple[torch.Tensor, torch
                                   _ptr(z_comb), _stream(z_vals.device))
     _l.check(st, 'sunerf_hier_resample')
     return new_z, z_comb
+
+
+WGRAD_SPLIT = 32    # partial sums per layer in sunerf_mlp_wgrad (9 layers x 32 = 288 workgroups >= 256 CUs)
+
+
+def emission_render_bwd(packed: PackedMLP, rays_o, rays_d, z_vals, raw, stash, g_image, g_reg, g_reg_const: float,
+                        reg_radius: float, grad_weights: Sequence[torch.Tensor], grad_biases: Sequence[torch.Tensor],
+                        accumulate: bool = False):
+    """Backward of one render pass: fills (or accumulates into) ``grad_weights[i]`` / ``grad_biases[i]`` (nn.Linear
+    layouts) from the gradient w.r.t. the 'image' output (N,) or (N,1) and the 'regularization' output
+    (``g_reg`` (N,S) tensor or None + the constant ``g_reg_const``)."""
+    lib = _l.load()
+    n, s = z_vals.shape
+    dev = z_vals.device
+    rays_o = _dev(rays_o, 'rays_o', (n, 3))
+    rays_d = _dev(rays_d, 'rays_d', (n, 3))
+    z_vals = _dev(z_vals, 'z_vals', (n, s))
+    raw = _dev(raw, 'raw', (n, s, 2))
+    g_image = _dev(g_image.reshape(-1), 'g_image', (n,))
+    if g_reg is not None:
+        g_reg = _dev(g_reg, 'g_reg', (n, s))
+    D, nl = packed.d_filter, packed.n_linear
+    g_raw = torch.empty(n, s, 2, dtype=torch.float32, device=dev)
+    absmax = torch.empty(1, dtype=torch.int32, device=dev)
+    stream = _stream(dev)
+    st = lib.sunerf_emission_integral_bwd(_ptr(raw), _ptr(z_vals), _ptr(rays_o), _ptr(rays_d), _ptr(g_image), _ptr(g_reg),
+                                          float(g_reg_const), float(reg_radius), n, s, _ptr(g_raw), _ptr(absmax), stream)
+    _l.check(st, 'sunerf_emission_integral_bwd')
+    dz = torch.empty(lib.sunerf_dz_stash_bytes(n, s, D, nl), dtype=torch.uint8, device=dev)
+    st = lib.sunerf_mlp_dgrad(_ptr(packed.transposed()), D, nl, _ptr(g_raw), _ptr(absmax), _ptr(stash), _ptr(dz), n, s,
+                              stream)
+    _l.check(st, 'sunerf_mlp_dgrad')
+    ws = torch.empty(lib.sunerf_wgrad_workspace_bytes(nl, WGRAD_SPLIT), dtype=torch.uint8, device=dev)
+    for i, (gw, gb) in enumerate(zip(grad_weights, grad_biases)):
+        d_in = 84 if i == 0 else D
+        d_o = packed.d_out if i == nl - 1 else D
+        if gw.shape != (d_o, d_in) or gb.shape != (d_o,) or not gw.is_contiguous() or gw.dtype != torch.float32:
+            raise ValueError(f'grad buffer {i} has the wrong shape / layout')
+    GW = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grad_weights])
+    GB = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grad_biases])
+    st = lib.sunerf_mlp_wgrad(D, nl, packed.d_out, _ptr(stash), _ptr(dz), _ptr(g_raw), _ptr(absmax), n, s, _ptr(ws),
+                              WGRAD_SPLIT, GW, GB, int(accumulate), stream)
+    _l.check(st, 'sunerf_mlp_wgrad')
+    return g_raw

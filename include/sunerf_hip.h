@@ -99,6 +99,42 @@ int sunerf_emission_render_fwd(const void* packed, int d_filter, int n_linear,
                                float reg_radius, void* act_stash, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Backward of the fused render pass (training).  The reference has no backward code of its own: these entry points
+ * replace what torch.autograd derives from base_tracing.py:118-129 + emission.py:14-54 + model.py:44-57 for the
+ * loss of sunerf/model/sunerf.py:110-120 (gradients w.r.t. the MLP parameters only: sampling.py:120 detaches the
+ * resampled z, so nothing flows to the ray geometry).  Call order for one pass:
+ *
+ *   sunerf_emission_render_fwd(..., act_stash != NULL)       forward, stashes fp16 sin / cos fragments
+ *   sunerf_emission_integral_bwd                             g_image (N), g_reg (N,S) -> g_raw (N,S,2), max |g_raw|
+ *   sunerf_mlp_dgrad                                         dZ of every layer -> dz_stash (fp16, scaled)
+ *   sunerf_mlp_wgrad                                         dW, db of every Linear layer (nn.Linear layouts)
+ *
+ *   packedT  : sunerf_pack_mlp_t output (transposed fp16 weight image), re-pack after every optimiser step
+ *   g_reg    : (N,S) gradient w.r.t. the 'regularization' output, or NULL with g_reg_const (the usual
+ *              lambda / (N*S) of regularization.mean(), sunerf.py:118-119)
+ *   g_absmax : 4-byte device scratch (bit pattern of max |g_raw|; selects the fp16 gradient scale on the device)
+ *   workspace: sunerf_wgrad_workspace_bytes(n_linear, split) bytes; split = number of partial sums per layer
+ *   accumulate != 0 adds to grad_* instead of overwriting (autograd .grad accumulation)
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t sunerf_packed_mlp_t_bytes(int d_filter, int n_linear);
+int sunerf_pack_mlp_t(const float* const* weights_host, int n_linear, int d_filter, int d_out, void* packedT,
+                      void* stream);
+size_t sunerf_dz_stash_bytes(int64_t n_rays, int n_samples, int d_filter, int n_linear);
+size_t sunerf_wgrad_workspace_bytes(int n_linear, int split);
+
+int sunerf_emission_integral_bwd(const float* raw, const float* z_vals, const float* rays_o, const float* rays_d,
+                                 const float* g_image, const float* g_reg, float g_reg_const, float reg_radius,
+                                 int64_t n_rays, int n_samples, float* g_raw, void* g_absmax, void* stream);
+
+int sunerf_mlp_dgrad(const void* packedT, int d_filter, int n_linear, const float* g_raw, const void* g_absmax,
+                     const void* act_stash, void* dz_stash, int64_t n_rays, int n_samples, void* stream);
+
+int sunerf_mlp_wgrad(int d_filter, int n_linear, int d_out, const void* act_stash, const void* dz_stash,
+                     const float* g_raw, const void* g_absmax, int64_t n_rays, int n_samples, void* workspace,
+                     int split, float* const* grad_weights_host, float* const* grad_biases_host, int accumulate,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Hierarchical (inverse-CDF) resampling + merge.
  * Replaces HierarchicalSampler.forward / sample_pdf, sampling.py:111-169 (perturb=False: u = linspace(0,1,S_f),
  * passed in as the tensor `u` [S_f] so that torch.linspace's own fp32 values are used; or a per-ray u [N,S_f]
