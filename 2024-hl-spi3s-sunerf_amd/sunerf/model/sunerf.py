@@ -1,0 +1,148 @@
+"""Mirror of the reference's ``sunerf/model/sunerf.py``: the Lightning-module API surface on the fused renderer.
+
+``pytorch_lightning`` is optional: when it is importable the modules subclass ``LightningModule`` (so
+``run_emission.py`` works unchanged); otherwise a minimal base with the same hook names is used and
+``fit_steps`` below drives ``training_step`` / ``configure_optimizers`` / ``on_train_batch_end`` directly.
+"""
+import os
+
+import torch
+from torch import nn
+from torch.optim.lr_scheduler import ExponentialLR
+
+from sunerf.rendering.base_tracing import SuNeRFRendering
+from sunerf.rendering.emission import EmissionRadiativeTransfer
+from sunerf.train.scaling import ImageAsinhScaling
+
+try:  # pragma: no cover - depends on the environment
+    from pytorch_lightning import LightningModule
+except Exception:  # ModuleNotFoundError in this image
+    class LightningModule(nn.Module):
+        """Stand-in with the hooks the reference modules use (log is a dict; no trainer)."""
+
+        def __init__(self):
+            super().__init__()
+            self.logged = {}
+
+        def log(self, name, value, **kwargs):
+            self.logged[name] = value
+
+
+class BaseSuNeRFModule(LightningModule):
+    """sunerf.py:15-59."""
+
+    def __init__(self, Rs_per_ds, seconds_per_dt, rendering: SuNeRFRendering, validation_dataset_mapping=None,
+                 lr_config=None):
+        super().__init__()
+        self.Rs_per_ds = Rs_per_ds
+        self.seconds_per_dt = seconds_per_dt
+        self.rendering = rendering
+        self.validation_dataset_mapping = validation_dataset_mapping
+        self.validation_outputs = {}
+        self.lr_config = {'start': 1e-4, 'end': 1e-5, 'iterations': 1e6} if lr_config is None else lr_config
+
+    def configure_optimizers(self):
+        self.optimizer = torch.optim.Adam(self.rendering.parameters(), lr=self.lr_config['start'])
+        self.scheduler = ExponentialLR(self.optimizer, gamma=(self.lr_config['end'] / self.lr_config['start']) ** (
+                1 / self.lr_config['iterations']))
+        return [self.optimizer], [self.scheduler]
+
+    def on_train_batch_end(self, *args, **kwargs):
+        if self.scheduler.get_last_lr()[0] > 5e-5:
+            self.scheduler.step()
+        self.log('Learning Rate', self.scheduler.get_last_lr()[0])
+
+    def validation_epoch_end(self, outputs_list):
+        if len(outputs_list) == 0:
+            return
+        self.validation_outputs = {}
+        if isinstance(outputs_list[0], dict):
+            outputs_list = [outputs_list]
+        if len(outputs_list) == 0 or any([len(o) == 0 for o in outputs_list]):
+            return
+        for i, outputs in enumerate(outputs_list):
+            out_keys = outputs[0].keys()
+            outputs = {k: torch.cat([o[k] for o in outputs]) for k in out_keys}
+            self.validation_outputs[self.validation_dataset_mapping[i]] = outputs
+
+    def on_load_checkpoint(self, checkpoint):
+        state_dict = checkpoint['state_dict']
+        self.load_state_dict(state_dict, strict=False)
+        self.validation_outputs = {}
+
+
+def save_state(sunerf: BaseSuNeRFModule, data_module, save_path):
+    """sunerf.py:62-74: pickles the rendering module + data configuration (the ``.snf`` file)."""
+    output_path = '/'.join(save_path.split('/')[0:-1])
+    os.makedirs(output_path, exist_ok=True)
+    torch.save({'rendering': sunerf.rendering, 'data_config': data_module.config, 'Rs_per_ds': data_module.Rs_per_ds,
+                'seconds_per_dt': data_module.seconds_per_dt, 'ref_time': data_module.ref_time}, save_path)
+
+
+class EmissionSuNeRFModule(BaseSuNeRFModule):
+    """sunerf.py:77-149."""
+
+    def __init__(self, Rs_per_ds, seconds_per_dt, image_scaling_config, lambda_image=1.0, lambda_regularization=1.0,
+                 sampling_config=None, hierarchical_sampling_config=None, model_config=None, **kwargs):
+        self.lambda_image = lambda_image
+        self.lambda_regularization = lambda_regularization
+        rendering = EmissionRadiativeTransfer(Rs_per_ds=Rs_per_ds, sampling_config=sampling_config,
+                                              hierarchical_sampling_config=hierarchical_sampling_config,
+                                              model_config=model_config)
+        super().__init__(Rs_per_ds=Rs_per_ds, seconds_per_dt=seconds_per_dt, rendering=rendering, **kwargs)
+        self.image_scaling = ImageAsinhScaling(**image_scaling_config)
+        self.mse_loss = nn.MSELoss()
+
+    def _loss(self, outputs, target_image):
+        target_image = self.image_scaling(target_image)
+        coarse_loss = self.mse_loss(self.image_scaling(outputs['coarse_image']), target_image)
+        fine_loss = self.mse_loss(self.image_scaling(outputs['fine_image']), target_image)
+        regularization_loss = outputs['regularization'].mean()
+        loss = (self.lambda_image * (coarse_loss + fine_loss) + self.lambda_regularization * regularization_loss)
+        return loss, coarse_loss, fine_loss, regularization_loss
+
+    def training_step(self, batch, batch_nb):
+        tracing = batch['tracing']
+        rays, time, target_image = tracing['rays'], tracing['time'], tracing['target_image']
+        rays_o, rays_d = rays[:, 0].contiguous(), rays[:, 1].contiguous()
+        outputs = self.rendering(rays_o, rays_d, time)
+
+        # one fused finite check instead of the reference's 16 host syncs (sunerf.py:105-107); same failure mode
+        finite = torch.stack([torch.isfinite(v).all() for v in outputs.values()]).all()
+        assert bool(finite), '! [Numerical Alert] an output contains NaN or Inf.'
+
+        loss, coarse_loss, fine_loss, regularization_loss = self._loss(outputs, target_image)
+        with torch.no_grad():
+            psnr = -10. * torch.log10(fine_loss)
+        self.log('loss', loss)
+        self.log('train', {'coarse': coarse_loss, 'fine': fine_loss, 'regularization': regularization_loss, 'psnr': psnr})
+        return loss
+
+    def validation_step(self, batch, batch_nb, **kwargs):
+        dataloader_idx = kwargs['dataloader_idx'] if 'dataloader_idx' in kwargs else 0
+        if dataloader_idx == 0:
+            rays, time, target_image = batch['rays'], batch['time'], batch['target_image']
+            rays_o, rays_d = rays[:, 0].contiguous(), rays[:, 1].contiguous()
+            with torch.no_grad():
+                outputs = self.rendering(rays_o, rays_d, time)
+            distance = rays_o.pow(2).sum(-1).pow(0.5)
+            return {'target_image': target_image, 'fine_image': outputs['fine_image'],
+                    'coarse_image': outputs['coarse_image'], 'height_map': outputs['height_map'],
+                    'absorption_map': outputs['absorption_map'], 'z_vals_stratified': outputs['z_vals_stratified'],
+                    'z_vals_hierarchical': outputs['z_vals_hierarchical'], 'distance': distance}
+
+
+def fit_steps(module: BaseSuNeRFModule, batches, gradient_clip_val=0.5):
+    """Minimal trainer loop with the semantics run_emission.py configures on the Lightning Trainer
+    (run_emission.py:65-75): backward, clip_grad_norm_(0.5), Adam step, on_train_batch_end."""
+    (optimizer,), _ = module.configure_optimizers()
+    losses = []
+    for i, batch in enumerate(batches):
+        optimizer.zero_grad(set_to_none=True)
+        loss = module.training_step(batch, i)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(module.rendering.parameters(), gradient_clip_val)
+        optimizer.step()
+        module.on_train_batch_end()
+        losses.append(loss.detach())
+    return losses

@@ -2,7 +2,7 @@
 import torch
 
 from sunerf.rendering.base_tracing import SuNeRFRendering
-from sunerf_hip import ops
+from sunerf.rendering.functional import emission_pass
 
 
 class EmissionRadiativeTransfer(SuNeRFRendering):
@@ -18,10 +18,9 @@ class EmissionRadiativeTransfer(SuNeRFRendering):
             raise ValueError('EmissionRadiativeTransfer takes no wavelengths')
         z_vals = self.sampler.z_vals(rays_o, rays_d)
         reg_radius = 1.2 / self.Rs_per_ds
-        coarse = ops.emission_render_fwd(self.coarse_model.packed(), rays_o, rays_d, times, z_vals, reg_radius)
-        new_z, z_comb = self.sampler_hierarchical.resample(z_vals, coarse['weights'])
-        fine = ops.emission_render_fwd(self.fine_model.packed(), rays_o, rays_d, times, z_comb, reg_radius,
-                                       want_epilogues=True)
+        coarse = emission_pass(self.coarse_model, rays_o, rays_d, times, z_vals, reg_radius, want_epilogues=False)
+        new_z, z_comb = self.sampler_hierarchical.resample(z_vals, coarse['weights'])   # no gradient (sampling.py:120)
+        fine = emission_pass(self.fine_model, rays_o, rays_d, times, z_comb, reg_radius, want_epilogues=True)
         return {'z_vals_stratified': z_vals, 'coarse_image': coarse['image'], 'z_vals_hierarchical': new_z,
                 'fine_image': fine['image'], 'image': fine['image'], 'height_map': fine['height_map'],
                 'absorption_map': fine['absorption_map'], 'regularization': fine['regularization']}

@@ -1,4 +1,4 @@
-"""Glue between the module API and the HIP kernels (forward orchestration; autograd lives here)."""
+"""Glue between the module API and the HIP kernels: forward orchestration and the autograd boundary."""
 import torch
 
 from sunerf_hip import ops
@@ -8,7 +8,7 @@ def mlp_points(model, x: torch.Tensor) -> torch.Tensor:
     """NeRF.forward on arbitrary query points (M, 4) -> (M, d_out) (model.py:44-57).
 
     Runs the fused render kernel with one two-sample "ray" per point (o = 0, d = xyz, z = 1 => o + d*z = xyz
-    exactly) and returns the raw MLP output of the first sample."""
+    exactly) and returns the raw MLP output of the first sample.  Inference only (no autograd)."""
     flat = x.reshape(-1, 4)
     m = flat.shape[0]
     o = torch.zeros(m, 3, dtype=torch.float32, device=flat.device)
@@ -16,3 +16,63 @@ def mlp_points(model, x: torch.Tensor) -> torch.Tensor:
     out = ops.emission_render_fwd(model.packed(), o, flat[:, :3].contiguous(), flat[:, 3].contiguous(), z,
                                   reg_radius=0., want_raw=True)
     return out['raw'][:, 0, :]
+
+
+class _EmissionPass(torch.autograd.Function):
+    """One fused render pass (coarse or fine) as an autograd node.
+
+    Differentiable outputs: ``image`` and ``regularization`` (the two the training loss of sunerf.py:110-120 uses);
+    gradients are produced for the MLP parameters only -- the reference's graph has no path to the rays
+    (sampling.py:120 detaches the resampled z).  ``weights`` / ``absorption`` / maps are marked non-differentiable."""
+
+    @staticmethod
+    def forward(ctx, model, rays_o, rays_d, times, z_vals, reg_radius, want_epilogues, *params):
+        training = any(ctx.needs_input_grad[7:])
+        packed = model.packed()
+        out = ops.emission_render_fwd(packed, rays_o, rays_d, times, z_vals, reg_radius,
+                                      want_epilogues=want_epilogues, training=training)
+        ctx.training = training
+        if training:
+            ctx.packed = packed
+            ctx.reg_radius = reg_radius
+            ctx.n_params = len(params)
+            ctx.param_meta = [(p.shape, p.device) for p in params]
+            ctx.save_for_backward(rays_o, rays_d, z_vals, out['raw'], out['stash'])
+        outs = [out['image'], out['weights'], out['absorption']]
+        non_diff = [out['weights'], out['absorption']]
+        if want_epilogues:
+            outs += [out['height_map'], out['absorption_map'], out['regularization']]
+            non_diff += [out['height_map'], out['absorption_map']]
+        ctx.mark_non_differentiable(*non_diff)
+        ctx.want_epilogues = want_epilogues
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_image, g_weights, g_absorption, g_hm=None, g_am=None, g_reg=None):
+        rays_o, rays_d, z_vals, raw, stash = ctx.saved_tensors
+        n, s = z_vals.shape
+        if g_image is None:
+            g_image = torch.zeros(n, dtype=torch.float32, device=z_vals.device)
+        # parameters arrive as (W0, b0, W1, b1, ...)
+        gW = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[0::2]]
+        gb = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[1::2]]
+        ops.emission_render_bwd(ctx.packed, rays_o, rays_d, z_vals, raw, stash, g_image, g_reg, 0.0, ctx.reg_radius,
+                                gW, gb)
+        grads = []
+        for w, b in zip(gW, gb):
+            grads += [w, b]
+        return (None,) * 7 + tuple(grads)
+
+
+def emission_pass(model, rays_o, rays_d, times, z_vals, reg_radius, want_epilogues):
+    """Dict of one pass' outputs; goes through autograd when gradients are enabled and the model is trainable."""
+    params = []
+    for lin in model.linears():
+        params += [lin.weight, lin.bias]
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        outs = _EmissionPass.apply(model, rays_o, rays_d, times, z_vals, reg_radius, want_epilogues, *params)
+        keys = ['image', 'weights', 'absorption'] + (['height_map', 'absorption_map', 'regularization']
+                                                     if want_epilogues else [])
+        return dict(zip(keys, outs))
+    return ops.emission_render_fwd(model.packed(), rays_o, rays_d, times, z_vals, reg_radius,
+                                   want_epilogues=want_epilogues)
