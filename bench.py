@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
-"""Headline benchmark: ray-samples/s of the fused emission renderer on MI355X.
+"""Headline benchmark: ray-samples/s (forward + backward) of the fused emission renderer on MI355X.
 
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank/GPU)
 
-One step = one pass of the hot path over this rank's batch of synthetic rays: a
-``--res`` x ``--res`` observer image (default 1024 x 1024), ``--samples`` samples per ray (default 128), 8 x 256 sine
-MLP, rays resident in HBM before the timed region.  Rays are sharded over ranks by image rows (weak scaling: every
-rank renders a full-size frame of its own at N > 1, so per-GPU work is fixed); value = ray-samples of all ranks /
-max-over-ranks wall time.
+Workload (BASELINE.json metric: ray-samples/sec/GPU (fwd+bwd), 1024^2 image x 128 samples): a synthetic 1024 x 1024
+observer frame, 128 samples per ray, 8 x 256 sine MLP, fp32 parameters.  One step = one optimiser
+step of the hot path on this rank's next batch of ``--batch`` rays (default 32768 = 1/32 of the frame) that are
+resident in HBM before the timed region: fused forward render (with activation stash), loss of sunerf.py:110-120
+(asinh-scaled MSE + regularization mean), backward (integral, dgrad, wgrad), gradient all-reduce over the ranks
+(RCCL), clip_grad_norm_(0.5) and Adam.  Rays are sharded over ranks by image rows, every rank works on equally sized
+batches of its own rows (weak scaling); value = ray-samples of all ranks / max-over-ranks wall time.
+``--mode fwd`` times the inference render of the whole frame instead (configs[1] of BASELINE.json).
 
 The JSON line carries
   roofline     : algorithmic GEMM FLOPs of the dominant kernel (sunerf_emission_render_fwd) per launch / its average
@@ -33,8 +36,9 @@ PEAK_F16_DENSE_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense BF16/F16 MFMA p
 PEAK_F32_MFMA_TFLOPS = 157.3
 
 
-def cpu_baseline(res, samples, seconds_budget=20.0):
-    """Times oracle/sunerf_oracle.py (kind 'port') on a bounded sample: a strip of rows of the same frame."""
+def cpu_baseline(res, samples, mode, seconds_budget=20.0):
+    """Times oracle/sunerf_oracle.py (kind 'port': the reference's aten op sequence) on a bounded sample of the same
+    workload: a strip of rays through the disk centre of the same frame; forward only or forward + backward."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import sunerf_oracle as orc
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -42,33 +46,56 @@ def cpu_baseline(res, samples, seconds_budget=20.0):
     torch.set_num_threads(cores)
     params = orc.init_params(D_FILTER, N_LAYERS, seed=7)
     o, d = orc.synthetic_rays(res)
-    n = 2048
+    n = 2048 if mode == 'fwd' else 1024
     start = (res // 2) * res                      # rows through the disk centre
     o, d = o[start:start + n].contiguous(), d[start:start + n].contiguous()
     t = torch.zeros(n, 1)
     z = orc.stratified_z(o, d, orc.linspace_t_vals(samples), torch.tensor(1.3), torch.tensor(1.0))
-    with torch.no_grad():
-        orc.render_pass(params, o[:256], d[:256], t[:256], z[:256])   # warm-up
-        best, spent, reps = float('inf'), 0.0, 0
-        while spent < seconds_budget and reps < 5:
-            t0 = time.perf_counter()
-            orc.render_pass(params, o, d, t, z)
-            dt = time.perf_counter() - t0
-            best = min(best, dt)
-            spent += dt
-            reps += 1
+    target = torch.rand(n, 1, generator=torch.Generator().manual_seed(1))
+    if mode == 'train':
+        for W, b in params:
+            W.requires_grad_(True)
+            b.requires_grad_(True)
+
+    def run(nn_):
+        if mode == 'fwd':
+            with torch.no_grad():
+                orc.render_pass(params, o[:nn_], d[:nn_], t[:nn_], z[:nn_])
+        else:
+            out = orc.render_pass(params, o[:nn_], d[:nn_], t[:nn_], z[:nn_])
+            dist_pts = out['points'].pow(2).sum(-1).pow(0.5)
+            reg = torch.relu(dist_pts - 1.2) * (1 - out['regularizing_quantity'])
+            loss = torch.nn.functional.mse_loss(orc.asinh_scaling(out['image']), orc.asinh_scaling(target[:nn_])) + reg.mean()
+            loss.backward()
+
+    run(128)   # warm-up
+    best, spent, reps = float('inf'), 0.0, 0
+    while spent < seconds_budget and reps < 5:
+        t0 = time.perf_counter()
+        run(n)
+        dt = time.perf_counter() - t0
+        best = min(best, dt)
+        spent += dt
+        reps += 1
     return {'value': n * samples / best, 'unit': 'ray-samples/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n} rays x {samples} samples (rows through disk centre of the {res}x{res} frame), '
-                      f'forward render pass, best of {reps}'}
+                      + ('forward render pass' if mode == 'fwd' else 'forward + loss + backward (autograd)')
+                      + f', best of {reps}'}
+
+
+FLOPS_BWD_PER_SAMPLE = 2 * ((N_LAYERS - 1) * D_FILTER * D_FILTER + D_FILTER * 2) \
+    + 2 * (ENC * D_FILTER + (N_LAYERS - 1) * D_FILTER * D_FILTER + D_FILTER * 2)          # dgrad + wgrad = 1 880 064
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--res', type=int, default=1024)
     ap.add_argument('--samples', type=int, default=128)
+    ap.add_argument('--batch', type=int, default=32768, help='rays per rank and optimiser step (train mode)')
+    ap.add_argument('--mode', choices=['train', 'fwd'], default='train')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -82,72 +109,113 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
 
     from sunerf.model.model import NeRF
+    from sunerf.rendering.functional import emission_pass
+    from sunerf.train.scaling import ImageAsinhScaling
     from sunerf_hip import ops
+    from sunerf_hip.dist import GradBucket, shard_range
     from sunerf_hip.rays import observer_rays
 
     torch.manual_seed(7)
     model = NeRF(d_input=4, d_output=2, n_layers=N_LAYERS, d_filter=D_FILTER).to(dev)
-    packed = model.packed()
-    # every rank renders a full frame seen from its own longitude (weak scaling)
-    rays_o, rays_d = observer_rays(args.res, theta=-0.3 + 0.05 * rank, device=dev)
-    n_rays = rays_o.shape[0]
-    times = torch.zeros(n_rays, device=dev)
     t_vals = torch.linspace(0., 1., args.samples, device=dev)
-    z_vals = ops.sample_z(ops.SAMPLER_STRATIFIED, rays_o, rays_d, t_vals, 1.3, 1.0)
-    torch.cuda.synchronize()
-
-    def step():
-        return ops.emission_render_fwd(packed, rays_o, rays_d, times, z_vals, reg_radius=1.2, want_epilogues=True)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    if args.mode == 'fwd':
+        # every rank renders a full frame seen from its own longitude
+        rays_o, rays_d = observer_rays(args.res, theta=-0.3 + 0.05 * rank, device=dev)
+        n_rays = rays_o.shape[0]
+        times = torch.zeros(n_rays, device=dev)
+        z_vals = ops.sample_z(ops.SAMPLER_STRATIFIED, rays_o, rays_d, t_vals, 1.3, 1.0)
+        packed = model.packed()
+        rays_per_step = n_rays
+
+        def step(i):
+            return ops.emission_render_fwd(packed, rays_o, rays_d, times, z_vals, reg_radius=1.2, want_epilogues=True)['image']
+        flops_per_sample, kernel_name = FLOPS_FWD_PER_SAMPLE, 'render_fwd_kernel<256, false>'
+    else:
+        # this rank's rows of the frame; batches of --batch rays cycle through them
+        r0, r1 = shard_range(args.res, rank, world)
+        rays_o, rays_d = observer_rays(args.res, row_start=r0, row_end=r1, device=dev)
+        n_local = rays_o.shape[0]
+        perm = torch.randperm(n_local, device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
+        rays_o, rays_d = rays_o[perm].contiguous(), rays_d[perm].contiguous()      # pre-shuffled ray pool
+        times = torch.rand(n_local, generator=torch.Generator().manual_seed(0)).to(dev)
+        target = torch.rand(n_local, 1, generator=torch.Generator().manual_seed(1)).to(dev)
+        z_all = ops.sample_z(ops.SAMPLER_STRATIFIED, rays_o, rays_d, t_vals, 1.3, 1.0)
+        B = min(args.batch, n_local)
+        n_batches = n_local // B
+        rays_per_step = B
+        scaling = ImageAsinhScaling(vmax=1, a=0.005).to(dev)
+        bucket = GradBucket(model.parameters())
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        tgt_scaled = scaling(target)
+
+        def step(i):
+            b = (i % n_batches) * B
+            sl = slice(b, b + B)
+            bucket.zero()
+            out = emission_pass(model, rays_o[sl], rays_d[sl], times[sl], z_all[sl], 1.2, want_epilogues=True)
+            loss = torch.nn.functional.mse_loss(scaling(out['image']), tgt_scaled[sl]) + out['regularization'].mean()
+            loss.backward()
+            bucket.gather_grads()
+            bucket.all_reduce_mean()
+            bucket.clip_grad_norm_(0.5)
+            opt.step()
+            return loss
+        flops_per_sample, kernel_name = FLOPS_FWD_PER_SAMPLE + FLOPS_BWD_PER_SAMPLE, 'render_fwd_kernel<256, true> + dgrad + wgrad'
+
+    for i in range(args.warmup):
+        step(i)
     barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record()          # on the current stream == the stream the kernel is launched on
-        out = step()
+        ev[i][0].record()          # on the current stream == the stream the kernels are launched on
+        out = step(args.warmup + i)
         ev[i][1].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    assert os.environ.get('SUNERF_DEBUG') or torch.isfinite(out['image']).all()
+    step_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    assert torch.isfinite(out).all()
 
     el = torch.tensor([elapsed], device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
-    samples_per_step = n_rays * args.samples * world
+    samples_per_step = rays_per_step * args.samples * world
     value = samples_per_step * args.steps / elapsed
 
     if rank == 0:
-        achieved = n_rays * args.samples * FLOPS_FWD_PER_SAMPLE / (kernel_ms * 1e-3) / 1e12
+        achieved = rays_per_step * args.samples * flops_per_sample / (step_ms * 1e-3) / 1e12
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get('render_fwd_bytes_per_launch')
+                traffic = json.load(f).get(f'{args.mode}_bytes_per_step')
+        what = 'fwd+bwd' if args.mode == 'train' else 'fwd'
         line = {
-            'metric': 'ray-samples/sec (fused emission render, fwd)', 'value': value, 'unit': 'ray-samples/s',
+            'metric': f'ray-samples/sec ({what}, fused emission renderer)', 'value': value, 'unit': 'ray-samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 (fp16 hi/lo split, 3 MFMA per product, fp32 accumulate)', 'data': 'synthetic',
-            'config': {'workload': f'emission render fwd, {args.res}x{args.res} rays x {args.samples} samples/ray, '
-                                   f'single fused pass, {N_LAYERS}x{D_FILTER} sine MLP, per GPU',
-                       'rays_per_gpu': n_rays, 'samples_per_ray': args.samples},
+            'dtype': 'f32 (forward: fp16 hi/lo split, 3 MFMA per product; backward: fp16 MFMA; fp32 accumulate and parameters)',
+            'data': 'synthetic',
+            'config': {'workload': (f'emission render {what}, {args.res}x{args.res} frame x {args.samples} samples/ray, '
+                                    f'{N_LAYERS}x{D_FILTER} sine MLP, '
+                                    + (f'{rays_per_step} rays per optimiser step and GPU (render+loss+backward+all-reduce+clip+Adam)'
+                                       if args.mode == 'train' else 'whole frame per step and GPU')),
+                       'rays_per_step_per_gpu': rays_per_step, 'samples_per_ray': args.samples, 'mode': args.mode},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F16_DENSE_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F16_DENSE_TFLOPS, 'traffic': traffic,
-                         'kernel': 'render_fwd_kernel<256>', 'kernel_ms': kernel_ms,
-                         'flops_per_sample': FLOPS_FWD_PER_SAMPLE, 'executed_over_algorithmic': 3.0,
+                         'kernel': kernel_name, 'step_ms_hip_events': step_ms,
+                         'flops_per_sample': flops_per_sample,
                          'frac_of_f32_mfma_peak': achieved / PEAK_F32_MFMA_TFLOPS},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(args.res, args.samples)
+            line['cpu_baseline'] = cpu_baseline(args.res, args.samples, args.mode)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
