@@ -165,7 +165,10 @@ def hier_resample(z_vals, weights, u: torch.Tensor) -> Tuple[torch.Tensor, torch
     return new_z, z_comb
 
 
-WGRAD_SPLIT = 32    # partial sums per layer in sunerf_mlp_wgrad (9 layers x 32 = 288 workgroups >= 256 CUs)
+def wgrad_split(n_linear: int, n_cus: int = 256) -> int:
+    """Partial sums per layer in sunerf_mlp_wgrad: n_linear * split workgroups must fit the chip in ONE wave (one
+    workgroup per CU, all about equally long): 9 layers -> 28 (252 workgroups); 288 would take two rounds."""
+    return max(1, n_cus // n_linear)
 
 
 def emission_render_bwd(packed: PackedMLP, rays_o, rays_d, z_vals, raw, stash, g_image, g_reg, g_reg_const: float,
@@ -195,7 +198,8 @@ def emission_render_bwd(packed: PackedMLP, rays_o, rays_d, z_vals, raw, stash, g
     st = lib.sunerf_mlp_dgrad(_ptr(packed.transposed()), D, nl, _ptr(g_raw), _ptr(absmax), _ptr(stash), _ptr(dz), n, s,
                               stream)
     _l.check(st, 'sunerf_mlp_dgrad')
-    ws = torch.empty(lib.sunerf_wgrad_workspace_bytes(nl, WGRAD_SPLIT), dtype=torch.uint8, device=dev)
+    split = wgrad_split(nl, torch.cuda.get_device_properties(dev).multi_processor_count)
+    ws = torch.empty(lib.sunerf_wgrad_workspace_bytes(nl, split), dtype=torch.uint8, device=dev)
     for i, (gw, gb) in enumerate(zip(grad_weights, grad_biases)):
         d_in = 84 if i == 0 else D
         d_o = packed.d_out if i == nl - 1 else D
@@ -204,6 +208,6 @@ def emission_render_bwd(packed: PackedMLP, rays_o, rays_d, z_vals, raw, stash, g
     GW = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grad_weights])
     GB = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grad_biases])
     st = lib.sunerf_mlp_wgrad(D, nl, packed.d_out, _ptr(stash), _ptr(dz), _ptr(g_raw), _ptr(absmax), n, s, _ptr(ws),
-                              WGRAD_SPLIT, GW, GB, int(accumulate), stream)
+                              split, GW, GB, int(accumulate), stream)
     _l.check(st, 'sunerf_mlp_wgrad')
     return g_raw
