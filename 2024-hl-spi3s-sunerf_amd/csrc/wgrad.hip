@@ -63,24 +63,23 @@ __device__ __forceinline__ half8 join(half4 lo, half4 hi) {
 
 constexpr int NBUF = 4;   // LDS ring of chunk buffers (3 chunks of HBM latency cover)
 
-template <int D>
-__global__ __launch_bounds__(WG_THREADS, 1) void wgrad_kernel(WgradArgs a) {
+// KIND: 0 = in layer (X = encoding, 6 fragments), 1 = hidden layer, 2 = out layer (dZ built from g_raw)
+template <int D, int KIND>
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, char* smem, int layer, int split) {
   constexpr int NT = D / 32, KS = D / 16;
   constexpr int QR = NT >= 4 ? 4 : NT;                      // tiles per quadrant side
   constexpr int BFR = KS > SUNERF_KS0 ? KS : SUNERF_KS0;    // B-side fragments per buffer
   constexpr int BUF = (KS + BFR) * 1024;                    // one chunk buffer: A fragments | B fragments
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // NBUF buffers + 1 KiB dummy target
+  constexpr int A_FRAGS = KIND == 2 ? 0 : KS;               // out layer: the A tile is built from g_raw, not DMA'd
+  constexpr int B_FRAGS = KIND == 0 ? SUNERF_KS0 : KS;
+  constexpr int ROW_TILES = KIND == 2 ? 1 : NT;
+  constexpr int COL_TILES = KIND == 0 ? SUNERF_KS0 / 2 : NT;
+  constexpr int PIECES = A_FRAGS + B_FRAGS;
+  constexpr int PW = (PIECES + 3) / 4;                      // DMA instructions per wave and chunk (uniform)
   const StashLayout SL(D, a.n_linear);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int layer = blockIdx.x / a.split, split = blockIdx.x % a.split;
   const int n_act = a.n_linear - 1;
-  const bool is_out = layer == a.n_linear - 1;
-  const bool is_in = layer == 0;
-  const int a_frags = is_out ? 0 : KS;                 // out layer: the A tile is built from g_raw, not DMA'd
-  const int b_frags = is_in ? SUNERF_KS0 : KS;
-  const int row_tiles = is_out ? 1 : NT;
-  const int col_tiles = is_in ? SUNERF_KS0 / 2 : NT;
   const size_t dz_chunk_bytes = (size_t)n_act * KS * 1024;
   const float gscale = gscale_from_bits(*a.g_absmax_bits);
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
@@ -89,19 +88,17 @@ __global__ __launch_bounds__(WG_THREADS, 1) void wgrad_kernel(WgradArgs a) {
   // tiles of this wave: rows [r0, r0 + nr), cols [c0, c0 + nc); waves of column quadrant 0 also own the bias column
   const int rq = wave >> 1, cq = wave & 1;
   const int r0 = rq * QR, c0 = cq * QR;
-  const int nr = max(0, min(QR, row_tiles - r0)), nc = max(0, min(QR, col_tiles - c0));
+  const int nr = max(0, min(QR, ROW_TILES - r0)), nc = max(0, min(QR, COL_TILES - c0));
   const bool do_bias = cq == 0 && nr > 0;
 
-  f32x16 acc[QR][QR], accb = {0};
+  f32x16 acc[QR][QR];     // the 16 tiles fill the 256 AGPRs exactly
+  float bsum[QR];         // db: per-lane partial sums of the A operand (row = lane & 31) over its 8-sample k slices
 #pragma unroll
   for (int i = 0; i < QR; ++i) {
+    bsum[i] = 0.f;
 #pragma unroll
     for (int j = 0; j < QR; ++j) acc[i][j] = (f32x16){0};
   }
-  // db = dZ . 1: one extra MFMA per row tile whose B operand is all ones in ONE column; row tile i uses column i of a
-  // single shared accumulator tile (rows = the tile's features, column i = its bias sums)
-  const _Float16 one_or_zero[QR] = {};
-  (void)one_or_zero;
 
   const int64_t per = (a.n_chunks_total + a.split - 1) / a.split;
   const int64_t cbeg = (int64_t)split * per, cend = min(a.n_chunks_total, cbeg + per);
@@ -111,42 +108,36 @@ __global__ __launch_bounds__(WG_THREADS, 1) void wgrad_kernel(WgradArgs a) {
   for (int off = tid * 16; off < a.lds_bytes; off += WG_THREADS * 16) *(f32x4*)(smem + off) = (f32x4){0, 0, 0, 0};
   __syncthreads();
 
-  // DMA of one chunk: (a_frags + b_frags) pieces of 1 KiB dealt round-robin to the 4 waves; every wave issues the same
-  // number PW of instructions (surplus ones re-read piece 0 into a dummy slot) so that vmcnt accounting is uniform
-  const int total_pieces = a_frags + b_frags;
-  const int PW = (total_pieces + 3) / 4;
+  // DMA of one chunk: PIECES pieces of 1 KiB dealt round-robin to the 4 waves; every wave issues the same number PW of
+  // instructions (surplus ones re-read piece 0 into a dummy slot) so that vmcnt accounting is uniform
+  const char* srcA0 = a.dz_stash + (size_t)layer * KS * 1024 + lane * 16;
+  const char* srcB0 = a.act_stash + (KIND == 0 ? 0 : SL.h_off(layer - 1)) + lane * 16;
+  const size_t act_chunk_bytes = SL.chunk_bytes();
   auto issue_chunk = [&](int64_t chunk, int buf) {
-    const char* srcA = a.dz_stash + chunk * dz_chunk_bytes + (size_t)layer * KS * 1024;
-    const char* srcB = a.act_stash + chunk * SL.chunk_bytes() + (is_in ? 0 : SL.h_off(layer - 1));
+    const char* srcA = srcA0 + chunk * dz_chunk_bytes;
+    const char* srcB = srcB0 + chunk * act_chunk_bytes;
     const unsigned dst0 = lds0 + buf * BUF;
+#pragma unroll
     for (int k = 0; k < PW; ++k) {
       const int p = k * 4 + wave;
-      const bool real = p < total_pieces;
-      const bool isA = p < a_frags;
-      const char* src = !real ? srcB : (isA ? srcA + (size_t)p * 1024 : srcB + (size_t)(p - a_frags) * 1024);
-      const unsigned dst = !real ? dummy : (isA ? dst0 + p * 1024 : dst0 + KS * 1024 + (p - a_frags) * 1024);
+      const bool real = p < PIECES;
+      const bool isA = p < A_FRAGS;
+      const char* src = !real ? srcB : (isA ? srcA + (size_t)p * 1024 : srcB + (size_t)(p - A_FRAGS) * 1024);
+      const unsigned dst = !real ? dummy : (isA ? dst0 + p * 1024 : dst0 + KS * 1024 + (p - A_FRAGS) * 1024);
       const unsigned dst_u = __builtin_amdgcn_readfirstlane(dst);
-      const char* src_l = src + lane * 16;
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src_l), "s"(dst_u) : "memory");
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst_u) : "memory");
     }
   };
-  // prologue: NBUF-1 chunks in flight
-  for (int k = 0; k < NBUF - 1; ++k)
-    if (k < n_my) issue_chunk(cbeg + k, k); else issue_chunk(cbeg, NBUF - 1 == 0 ? 0 : k);   // keep the op count uniform
+  // prologue: NBUF-1 chunks in flight (surplus issues re-read the first chunk: keeps the op count uniform)
+  for (int k = 0; k < NBUF - 1; ++k) issue_chunk(k < n_my ? cbeg + k : cbeg, k);
   const unsigned laneoff = tr_lane_offset(lane);
 
   for (int64_t it = 0; it < n_my; ++it) {
-    const int buf = (int)(it % NBUF);
+    const int buf = (int)(it & (NBUF - 1));
     const int64_t chunk = cbeg + it;
     // chunk `it` has landed when at most the (NBUF-2) younger chunks are outstanding
-    if (PW * (NBUF - 2) == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (PW * (NBUF - 2) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (PW * (NBUF - 2) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (PW * (NBUF - 2) == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (PW * (NBUF - 2) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (PW * (NBUF - 2) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (is_out) {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PW * (NBUF - 2)) : "memory");
+    if (KIND == 2) {
       // A tile of the out layer: "features" 0 / 1 = d loss / d raw[..., 0 / 1] (fragment order index 16 s + 8 h + e ->
       // s = 0, h = 0, e = 0 / 1), 32 samples; written by the first 128 threads (2 fragments x 64 lanes)
       if (tid < 128) {
@@ -166,7 +157,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void wgrad_kernel(WgradArgs a) {
     __syncthreads();   // everyone's pieces of chunk `it` landed; everyone finished chunk it-1 (its buffer is refilled next)
     {
       const int64_t nxt = it + NBUF - 1;
-      issue_chunk(nxt < n_my ? cbeg + nxt : cbeg, nxt < n_my ? (int)(nxt % NBUF) : (int)((it + NBUF - 1) % NBUF));
+      issue_chunk(nxt < n_my ? cbeg + nxt : cbeg, (int)(nxt & (NBUF - 1)));
     }
     const unsigned bufA = lds0 + buf * BUF + laneoff, bufB = bufA + KS * 1024;
     // ---- per k-step (16 samples): batch of transposed operand reads, one wait, 16 (+4 bias) MFMAs ----
@@ -193,9 +184,13 @@ __global__ __launch_bounds__(WG_THREADS, 1) void wgrad_kernel(WgradArgs a) {
         const half8 af = join(alo[i], ahi[i]);
 #pragma unroll
         for (int j = 0; j < QR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[j], acc[i][j], 0, 0, 0);
-        const _Float16 o = ((lane & 31) == i) ? (_Float16)1 : (_Float16)0;
-        const half8 ones = {o, o, o, o, o, o, o, o};
-        accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, ones, accb, 0, 0, 0);
+        // db = sum over samples of dZ: four v_dot2_f32_f16 against (1, 1) per operand (fp32 accumulate)
+        const half2v one2 = {(_Float16)1, (_Float16)1};
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const half2v pr = {af[e], af[e + 1]};
+          bsum[i] = __builtin_amdgcn_fdot2(pr, one2, bsum[i], false);
+        }
       }
     }
   }
@@ -214,11 +209,22 @@ __global__ __launch_bounds__(WG_THREADS, 1) void wgrad_kernel(WgradArgs a) {
         }
     }
   }
-  if (do_bias) {   // shared bias tile of this wave's row quadrant: column i <-> row tile r0 + i
-    float* t = out + ((size_t)r0 * 9 + 8) * 1024;
+  if (do_bias) {   // lanes l and l + 32 hold the two k halves of row l: combine, store 32 sums per row tile
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r * 64 + lane] = accb[r];
+    for (int i = 0; i < QR; ++i) {
+      const float v = bsum[i] + __shfl_xor(bsum[i], 32);
+      if (i < nr && lane < 32) out[((size_t)(r0 + i) * 9 + 8) * 1024 + lane] = v;
+    }
   }
+}
+
+template <int D>
+__global__ __launch_bounds__(WG_THREADS, 1) void wgrad_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // NBUF chunk buffers + 1 KiB dummy target + slack
+  const int layer = blockIdx.x / a.split, split = blockIdx.x % a.split;
+  if (layer == 0) wgrad_body<D, 0>(a, smem, layer, split);
+  else if (layer == a.n_linear - 1) wgrad_body<D, 2>(a, smem, layer, split);
+  else wgrad_body<D, 1>(a, smem, layer, split);
 }
 
 // feature of fragment-order index f (= 16 s + 8 h + e) on the activation side / the encoding side
@@ -248,20 +254,20 @@ __global__ void reduce_grads_kernel(ReduceArgs a) {
   const int lane = idx & 63, reg = (idx >> 6) & 15, t = idx >> 10;
   const int tr = t / 9, tc = t % 9;
   if (tc != 8 && tc >= col_tiles) return;
-  const int fa = 32 * tr + acc_row(reg, lane >> 5);     // fragment-order index on the dZ side
-  const int j = (layer == a.n_linear - 1) ? fa : frag_feature_hidden(fa);   // out layer: feature index = output index
-  if (j >= rows) return;
   int k = 0;
-  const int QR = (D / 32) >= 4 ? 4 : (D / 32);
-  const int tr_store = (tc == 8) ? (tr / QR) * QR : tr;  // bias sums of a row quadrant share one tile stored at its base
-  if (tc == 8) {
-    if ((lane & 31) != tr - tr_store) return;           // ... row tile tr owns column (tr - quadrant base)
+  int fa_row = acc_row(reg, lane >> 5);
+  if (tc == 8) {                                        // bias slot: 32 plain sums per row tile (reg 0, lanes 0..31)
+    if (reg != 0 || lane >= 32) return;
+    fa_row = lane;
   } else {
     const int fb = 32 * tc + (lane & 31);               // fragment-order index on the X side
     k = (layer == 0) ? frag_feature_enc(fb) : frag_feature_hidden(fb);
     if (k < 0 || k >= cols) return;
   }
-  const float* p = a.partial + (size_t)layer * a.split * 72 * 1024 + ((size_t)tr_store * 9 + tc) * 1024 + reg * 64 + lane;
+  const int fa = 32 * tr + fa_row;                      // fragment-order index on the dZ side
+  const int j = (layer == a.n_linear - 1) ? fa : frag_feature_hidden(fa);   // out layer: feature index = output index
+  if (j >= rows) return;
+  const float* p = a.partial + (size_t)layer * a.split * 72 * 1024 + ((size_t)tr * 9 + tc) * 1024 + reg * 64 + lane;
   float sum = 0.f;
   for (int s = 0; s < a.split; ++s) sum += p[(size_t)s * 72 * 1024];
   const float m = __uint_as_float(*a.g_absmax_bits);
