@@ -121,3 +121,25 @@ def test_shard_range_partitions():
         assert blocks[0][0] == 0 and blocks[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
         assert max(e - b for b, e in blocks) - min(e - b for b, e in blocks) <= 1
+
+
+def test_package_merges_with_a_reference_checkout(tmp_path):
+    """with our package root first and a reference checkout later on PYTHONPATH, mirrored modules
+    come from here and everything else (data loaders, run scripts) from the checkout."""
+    import subprocess
+    import sys
+    ref = tmp_path / 'checkout'
+    (ref / 'sunerf' / 'train').mkdir(parents=True)
+    (ref / 'sunerf' / 'data').mkdir(parents=True)
+    for d in ('sunerf', 'sunerf/train', 'sunerf/data'):
+        (ref / d / '__init__.py').write_text('')
+    (ref / 'sunerf' / 'train' / 'sampling.py').write_text('ORIGIN = "checkout"\n')
+    (ref / 'sunerf' / 'train' / 'callback.py').write_text('ORIGIN = "checkout"\n')
+    (ref / 'sunerf' / 'data' / 'dataset.py').write_text('ORIGIN = "checkout"\n')
+    (ref / 'sunerf' / 'run_emission.py').write_text('ORIGIN = "checkout"\n')
+    code = ('import sunerf.train.sampling as s, sunerf.train.callback as c, sunerf.data.dataset as d, sunerf.run_emission as r;'
+            'assert hasattr(s, "StratifiedSampler") and not hasattr(s, "ORIGIN");'
+            'assert c.ORIGIN == d.ORIGIN == r.ORIGIN == "checkout"; print("ok")')
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, '2024-hl-spi3s-sunerf_amd'), str(ref)]))
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True)
+    assert out.returncode == 0 and 'ok' in out.stdout, out.stderr
