@@ -146,6 +146,36 @@ def main():
 
     e2e('g5_emission_e2e', 64, 6, 32, 32, True)
     e2e('g5b_emission_d256', 256, 4, 32, 64, False)
+
+    # ---- G6 density-temperature head (run_density_temperature.py path): NeRF_DT + DT integral, 7 wavelengths, a row
+    #      block with absent channels (wavelength 0); loss = MSE (sunerf.py:187-195); Interp1D restated (parity unpinned)
+    DT = ref.rendering.density_temperature.DensityTemperatureRadiativeTransfer
+    torch.manual_seed(7)
+    dt = DT(Rs_per_ds=1.0, sampling_config={'type': 'stratified', 'n_samples': 16, 'perturb': False},
+            hierarchical_sampling_config={'type': 'hierarchical', 'n_samples': 16},
+            model_config={'d_filter': 64}, model=M.NeRF_DT, device=torch.device('cpu'), pixel_intensity_factor=1e17)
+    with torch.no_grad():      # make absorption and both relu branches matter
+        for m_ in (dt.coarse_model, dt.fine_model):
+            for k_, v_ in zip(m_.log_absortpion.keys(), (2e-6, 4e-6, -1e-6, 3e-6, 5e-6, 1e-6, 2e-6)):
+                m_.log_absortpion[k_].fill_(v_)
+            m_.volumetric_constant.fill_(1.5)
+            m_.out_layer.weight.mul_(6.0)
+    o, d, t = test_rays(4, 9)
+    wl = torch.tensor([94., 131., 171., 193., 211., 304., 335.]).repeat(o.shape[0], 1)
+    wl[3:6, 2] = 0.
+    wl[5:9, 5] = 0.
+    outputs = dt(o, d, t, wl)
+    target = torch.rand(o.shape[0], 7, generator=torch.Generator().manual_seed(2))
+    mse = torch.nn.MSELoss()
+    loss = mse(outputs['coarse_image'], target) + mse(outputs['fine_image'], target) + outputs['regularization'].mean()
+    loss.backward()
+    logte, tresp = orc.read_aia_response_genx(os.path.join(ref_import.REFERENCE_ROOT, 'sunerf/data/aia_temp_resp.genx'))
+    arrays = dict(rays_o=o, rays_d=d, times=t, wavelengths=wl, target=target, loss=loss, t_vals=dt.sampler.t_vals,
+                  aia_logte=logte, aia_tresp=tresp, aia_exp_time=2.9, pixel_intensity_factor=1e17)
+    arrays.update({'out__' + k: v for k, v in outputs.items()})
+    arrays.update(state_arrays('sd__', dt))
+    arrays.update({'grad__' + k.replace('.', '__'): p.grad for k, p in dt.named_parameters()})
+    npz('g6_dt_e2e', **arrays)
     ref_import.release_reference()
 
 

@@ -17,18 +17,86 @@ Two things are needed to make the reference importable here (SURVEY.md section 8
 """
 import sys
 import types
-from unittest import mock
 
 REFERENCE_ROOT = '/root/reference'
+
+
+class _Unit:
+    """Just enough of astropy.units for the class bodies the hot path imports (stellar_model.py:8-9) and for
+    ``(1*u.solRad).to(u.cm).value`` (density_temperature.py:231): a unit is a scale to CGS-ish base numbers."""
+
+    def __init__(self, scale=1.0):
+        self.scale = scale
+
+    def __rmul__(self, v):
+        return _Quantity(v * self.scale)
+
+    def __mul__(self, o):
+        return _Unit(self.scale * (o.scale if isinstance(o, _Unit) else o))
+
+    def __rtruediv__(self, v):
+        return _Quantity(v / self.scale)
+
+    def __truediv__(self, o):
+        return _Unit(self.scale / (o.scale if isinstance(o, _Unit) else o))
+
+    def __pow__(self, n):
+        return _Unit(self.scale ** n)
+
+
+class _Quantity:
+    def __init__(self, base):
+        self.base = base
+
+    def to(self, unit):
+        q = _Quantity(self.base)
+        q._unit = unit
+        return q
+
+    @property
+    def value(self):
+        return self.base / getattr(self, '_unit', _Unit()).scale
 
 
 def _install_stubs():
     if 'astropy' not in sys.modules:
         astropy = types.ModuleType('astropy')
-        units = mock.MagicMock(name='astropy.units')
+        units = types.ModuleType('astropy.units')
+        units.cm = _Unit(1.0)
+        units.Mm = _Unit(1e8)
+        units.solRad = _Unit(6.957e10)      # IAU 2015 nominal solar radius in cm
+        units.K = _Unit(1.0)
         astropy.units = units
         sys.modules['astropy'] = astropy
         sys.modules['astropy.units'] = units
+    if 'sunpy' not in sys.modules:
+        # density_temperature.py:4-5 -- sunpy.io.special.read_genx and xitorch.interpolate.Interp1D are not installed.
+        # read_genx is pure deserialisation (restated by oracle.read_aia_response_genx); Interp1D is restated from its
+        # documented semantics (linear, extrap=0) -- PARITY UNPINNED for that sub-step, see sunerf_oracle.py.
+        import os
+        import sunerf_oracle as orc
+
+        def read_genx(path):
+            if not os.path.isabs(path):
+                path = os.path.join(REFERENCE_ROOT, path)      # the reference opens it relative to the cwd
+            logte, tresp = orc.read_aia_response_genx(path)
+            out = {'HEADER': {}}
+            for c, w in enumerate(orc.AIA_WAVELENGTHS):
+                out[f'A{w}'] = {'LOGTE': logte[c], 'TRESP': tresp[c]}
+            return out
+
+        class Interp1D:
+            def __init__(self, x, y, method='linear', extrap=0):
+                assert method == 'linear' and extrap == 0
+                self.x, self.y = x, y
+
+            def __call__(self, xq):
+                return orc.interp1d_linear_extrap0(self.x, self.y, xq)
+
+        for name in ('sunpy', 'sunpy.io', 'sunpy.io.special', 'xitorch', 'xitorch.interpolate'):
+            sys.modules[name] = types.ModuleType(name)
+        sys.modules['sunpy.io.special'].read_genx = read_genx
+        sys.modules['xitorch.interpolate'].Interp1D = Interp1D
 
 
 def import_reference():
@@ -47,6 +115,7 @@ def import_reference():
         import sunerf.rendering.base_tracing  # noqa: F401
         import sunerf.rendering.emission  # noqa: F401
         import sunerf.train.scaling  # noqa: F401
+        import sunerf.rendering.density_temperature  # noqa: F401
         import sunerf
         assert sunerf.__file__.startswith(REFERENCE_ROOT), sunerf.__file__
         return sunerf

@@ -297,3 +297,104 @@ def synthetic_rays(resolution: int, theta: float = -0.3, phi: float = 0.1, radiu
     rays_d = torch.sum(directions[..., None, :] * c2w[:3, :3], dim=-1).reshape(-1, 3)
     rays_o = c2w[:3, -1].expand(rays_d.shape).contiguous()
     return rays_o, rays_d.contiguous()
+
+
+# --------------------------------------------------------------------------------------------------------------
+# density / temperature head -- sunerf/rendering/density_temperature.py, sunerf/model/model.py:136-187
+# --------------------------------------------------------------------------------------------------------------
+AIA_WAVELENGTHS = (94, 131, 171, 193, 211, 304, 335)
+
+
+def read_aia_response_genx(path: str):
+    """The AIA temperature-response table the reference loads with ``sunpy.io.special.read_genx``
+    (density_temperature.py:131).  IDL ``savegen`` / XDR big-endian file: every channel structure ``A<wl>`` holds
+    ``LOGTE float32[101]`` followed by ``TRESP float64[101]`` starting 32 bytes after the second occurrence of its
+    4-byte padded tag (offsets 1184, 2436, ... verified against the file length 9908 in SURVEY.md section 8a-6).
+    Returns (logte float32 [7, 101], tresp float64 [7, 101])."""
+    import numpy as np
+    raw = open(path, 'rb').read()
+    logte, tresp = [], []
+    for wl in AIA_WAVELENGTHS:
+        tag = ('A%d' % wl).encode().ljust(4, b'\x00')
+        first = raw.find(tag)
+        second = raw.find(tag, first + 4)
+        off = second + 32
+        lt = np.frombuffer(raw, dtype='>f4', count=101, offset=off).astype(np.float32)
+        tr = np.frombuffer(raw, dtype='>f8', count=101, offset=off + 404).astype(np.float64)
+        assert abs(lt[0] - 4.0) < 1e-6 and abs(lt[-1] - 9.0) < 1e-5 and np.all(np.diff(lt) > 0), 'unexpected genx layout'
+        logte.append(lt)
+        tresp.append(tr)
+    return np.stack(logte), np.stack(tresp)
+
+
+def interp1d_linear_extrap0(x: torch.Tensor, y: torch.Tensor, xq: torch.Tensor) -> torch.Tensor:
+    """Restatement of ``xitorch.interpolate.Interp1D(x, y, method='linear', extrap=0)`` (density_temperature.py:144-146):
+    piecewise-linear inside [x[0], x[-1]], 0 outside.  xitorch is not installed and no reference test pins it:
+    PARITY UNPINNED for this sub-step (from-documentation semantics)."""
+    idx = torch.searchsorted(x, xq.contiguous(), right=True) - 1
+    idx = idx.clamp(0, x.numel() - 2)
+    x0, x1, y0, y1 = x[idx], x[idx + 1], y[idx], y[idx + 1]
+    val = y0 + (xq - x0) * (y1 - y0) / (x1 - x0)
+    inside = (xq >= x[0]) & (xq <= x[-1])
+    return torch.where(inside, val, torch.zeros_like(val))
+
+
+def dt_integral(inferences: torch.Tensor, log_abs: Dict[str, torch.Tensor], vol_c: torch.Tensor, z_vals: torch.Tensor,
+                wavelengths: torch.Tensor, logte: torch.Tensor, resp: torch.Tensor,
+                pixel_intensity_factor: float) -> Dict[str, torch.Tensor]:
+    """DensityTemperatureRadiativeTransfer.raw2outputs, density_temperature.py:192-271 (the unused cm-``dists`` of
+    :223-232 dropped, defect D4).  ``logte`` (7,101) / ``resp`` (7,101) fp32 = table x aia_exp_time, as :137-146 build."""
+    wl = wavelengths[:, None, :].expand(wavelengths.shape[0], inferences.shape[1], wavelengths.shape[1])
+    density = torch.exp(torch.nn.functional.relu(inferences[..., 0]))
+    density = density[:, :, None].expand(-1, -1, wl.shape[2])
+    log_temperature = torch.nn.functional.relu(inferences[..., 1])
+    log_temperature = log_temperature[:, :, None].expand(-1, -1, wl.shape[2])
+    temperature_response = torch.zeros_like(log_temperature)
+    absorption_coefficients = torch.zeros_like(wl).float()
+    for c, w in enumerate(AIA_WAVELENGTHS):
+        sel = wl == float(w)
+        if sel.any():
+            tmp = interp1d_linear_extrap0(logte[c], resp[c], log_temperature.flatten()).reshape(temperature_response.shape)
+            temperature_response = torch.where(sel, tmp, temperature_response)
+            absorption_coefficients = torch.where(sel, torch.nn.functional.relu(log_abs[str(w)]).expand_as(wl), absorption_coefficients)
+    absorption = density * absorption_coefficients
+    absorption_integral = torch.cumulative_trapezoid(absorption, x=z_vals[:, :, None], dim=1)
+    emission = density.pow(2) * temperature_response
+    pixel_intensity_term = torch.exp(-absorption_integral) * emission[:, 0:-1, :]
+    pixel_intensity = torch.trapezoid(pixel_intensity_term, x=z_vals[:, 0:-1, None], dim=1) * vol_c * pixel_intensity_factor
+    weights = torch.nn.functional.relu(inferences[..., 0])
+    weights = weights / (weights.sum(1)[:, None] + 1e-10)
+    return {'image': pixel_intensity, 'weights': weights,
+            'regularizing_quantity': torch.nn.functional.relu(inferences[..., 0])}
+
+
+def render_pass_dt(params: Params, log_abs, vol_c, rays_o, rays_d, times, z_vals, wavelengths, logte, resp,
+                   pixel_intensity_factor, base_log_density: float = 10.0, base_log_temperature: float = 5.0):
+    """DT ``_render`` (density_temperature.py:148-190) with NeRF_DT.forward (model.py:169-187)."""
+    pts = points_on_rays(rays_o, rays_d, z_vals)
+    query = torch.cat([pts, times[:, None].repeat(1, pts.shape[1], 1)], -1)
+    x = mlp_forward(params, query.view(-1, 4))
+    x = torch.stack([x[:, 0] + base_log_density, x[:, 1] + base_log_temperature], -1)
+    inferences = x.reshape(*query.shape[:-1], -1)
+    out = dt_integral(inferences, log_abs, vol_c, z_vals, wavelengths, logte, resp, pixel_intensity_factor)
+    out['inferences'] = inferences
+    out['points'] = pts
+    return out
+
+
+def render_dt(coarse: Params, fine: Params, log_abs_c, vol_c_c, log_abs_f, vol_c_f, rays_o, rays_d, times, wavelengths,
+              logte, resp, *, Rs_per_ds=1., n_coarse=64, n_fine=128, distance=1.3, pixel_intensity_factor=1e10,
+              t_vals=None) -> Dict[str, torch.Tensor]:
+    """SuNeRFRendering.forward (base_tracing.py:46-111) for the DT subclass (regularization: density_temperature.py:273-274)."""
+    t_vals = linspace_t_vals(n_coarse) if t_vals is None else t_vals
+    z_vals = stratified_z(rays_o, rays_d, t_vals, torch.tensor(distance / Rs_per_ds, dtype=torch.float32),
+                          torch.tensor(1 / Rs_per_ds, dtype=torch.float32))
+    c = render_pass_dt(coarse, log_abs_c, vol_c_c, rays_o, rays_d, times, z_vals, wavelengths, logte, resp, pixel_intensity_factor)
+    new_z, z_comb = hierarchical_z(z_vals, c['weights'], n_fine)
+    f = render_pass_dt(fine, log_abs_f, vol_c_f, rays_o, rays_d, times, z_comb, wavelengths, logte, resp, pixel_intensity_factor)
+    q = f['regularizing_quantity']
+    dist_pts = f['points'].pow(2).sum(-1).pow(0.5)
+    return {'z_vals_stratified': z_vals, 'coarse_image': c['image'], 'z_vals_hierarchical': new_z, 'fine_image': f['image'],
+            'image': f['image'], 'height_map': (f['weights'] * dist_pts).sum(-1), 'absorption_map': (1 - q).sum(-1),
+            'regularization': torch.relu(dist_pts - 1.25 / Rs_per_ds) * torch.relu(q),
+            '_z_vals_combined': z_comb, '_fine_inferences': f['inferences'], '_coarse_weights': c['weights']}

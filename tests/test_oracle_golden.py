@@ -113,3 +113,38 @@ def test_synthetic_rays_hit_fraction():
     assert 0.55 < hit < 0.75      # ~ pi/2.2^2 of the field of view is on disk
     assert torch.isfinite(z).all()
     assert abs(d.norm(dim=-1).mean().item() - 1.0) < 1e-5
+
+
+def _dt_inputs(g):
+    logte = g['aia_logte'].float()
+    resp = (g['aia_tresp'] * float(g['aia_exp_time'])).float()          # density_temperature.py:141-145
+    def head(prefix):
+        la = {str(w): g[f'sd__{prefix}__log_absortpion__{w}'].clone() for w in orc.AIA_WAVELENGTHS}
+        return la, g[f'sd__{prefix}__volumetric_constant'].clone()
+    return logte, resp, head('coarse_model'), head('fine_model')
+
+
+def test_g6_density_temperature_end_to_end():
+    """DT head vs the reference run with the restated Interp1D / read_genx stubs (xitorch: parity unpinned)."""
+    g = load_golden('g6_dt_e2e')
+    coarse = params_from_golden(g, 'sd__coarse_model__')
+    fine = params_from_golden(g, 'sd__fine_model__')
+    logte, resp, (la_c, vc_c), (la_f, vc_f) = _dt_inputs(g)
+    leaves = [t for W, b in coarse + fine for t in (W, b)] + list(la_c.values()) + list(la_f.values()) + [vc_c, vc_f]
+    for t in leaves:
+        t.requires_grad_(True)
+    out = orc.render_dt(coarse, fine, la_c, vc_c, la_f, vc_f, g['rays_o'], g['rays_d'], g['times'], g['wavelengths'], logte,
+                        resp, n_coarse=16, n_fine=16, pixel_intensity_factor=float(g['pixel_intensity_factor']),
+                        t_vals=g['t_vals'])
+    for k in ['z_vals_stratified', 'coarse_image', 'z_vals_hierarchical', 'fine_image', 'image', 'height_map',
+              'absorption_map', 'regularization']:
+        exact(out[k], g['out__' + k])
+    mse = torch.nn.MSELoss()
+    loss = mse(out['coarse_image'], g['target']) + mse(out['fine_image'], g['target']) + out['regularization'].mean()
+    exact(loss, g['loss'])
+    loss.backward()
+    close(vc_f.grad, g['grad__fine_model__volumetric_constant'])
+    close(la_c['193'].grad, g['grad__coarse_model__log_absortpion__193'])
+    close(la_f['171'].grad, g['grad__fine_model__log_absortpion__171'])        # relu(negative) -> zero gradient
+    close(fine[0][0].grad, g['grad__fine_model__in_layer__1__weight'])
+    close(coarse[-1][1].grad, g['grad__coarse_model__out_layer__bias'])
