@@ -9,10 +9,10 @@ COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in architectural VGPRs.  The render / dgrad kernels keep their activation
 # fragments in the AGPR half of the register file (see render_fwd.hip), so this removes a v_accvgpr_read per accumulator
 # element from every tile epilogue.  wgrad.hip holds 256 accumulator registers per lane and wants them in AGPRs.
-for f in pack sampler render_fwd render_bwd; do
+for f in pack sampler render_fwd render_bwd dt; do
   hipcc $COMMON -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c -o "$OBJ/$f.o" "$f.hip" &
 done
 hipcc $COMMON "$@" -c -o "$OBJ/wgrad.o" wgrad.hip &
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/pack.o "$OBJ"/sampler.o "$OBJ"/render_fwd.o "$OBJ"/render_bwd.o "$OBJ"/wgrad.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/pack.o "$OBJ"/sampler.o "$OBJ"/render_fwd.o "$OBJ"/render_bwd.o "$OBJ"/dt.o "$OBJ"/wgrad.o
 echo "built $OUT"

@@ -129,7 +129,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, char* smem, int l
     }
   };
   // prologue: NBUF-1 chunks in flight (surplus issues re-read the first chunk: keeps the op count uniform)
-  for (int k = 0; k < NBUF - 1; ++k) issue_chunk(k < n_my ? cbeg + k : cbeg, k);
+  // (a workgroup whose slice is empty -- fewer chunks than workgroups -- must still read inside the stash)
+  const int64_t safe = min(cbeg, a.n_chunks_total - 1);
+  for (int k = 0; k < NBUF - 1; ++k) issue_chunk(k < n_my ? cbeg + k : safe, k);
   const unsigned laneoff = tr_lane_offset(lane);
 
   for (int64_t it = 0; it < n_my; ++it) {
@@ -157,7 +159,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, char* smem, int l
     __syncthreads();   // everyone's pieces of chunk `it` landed; everyone finished chunk it-1 (its buffer is refilled next)
     {
       const int64_t nxt = it + NBUF - 1;
-      issue_chunk(nxt < n_my ? cbeg + nxt : cbeg, (int)(nxt & (NBUF - 1)));
+      issue_chunk(nxt < n_my ? cbeg + nxt : safe, (int)(nxt & (NBUF - 1)));
     }
     const unsigned bufA = lds0 + buf * BUF + laneoff, bufB = bufA + KS * 1024;
     // ---- per k-step (16 samples): batch of transposed operand reads, one wait, 16 (+4 bias) MFMAs ----

@@ -82,3 +82,29 @@ class NeRF(nn.Module):
         """(M, 4) query points -> {'inferences': (M, d_output)} (model.py:44-57)."""
         from sunerf.rendering.functional import mlp_points
         return {'inferences': mlp_points(self, x)}
+
+
+class NeRF_DT(NeRF):
+    """model.py:136-187: the same MLP read as (log density, log temperature) with base offsets, plus the 7 per-channel
+    absorption scalars and the volumetric constant (same parameter names: ``log_absortpion.<wl>``, ``volumetric_constant``).
+    The offsets are applied inside the DT integral kernel (``sunerf_dt_integral_fwd``)."""
+
+    def __init__(self, d_input: int = 4, d_output: int = 2, n_layers: int = 8, d_filter: int = 512,
+                 skip: Tuple[int] = (), encoding='positional', base_log_temperature: float = 5.0,
+                 base_log_density: float = 10.0):
+        super().__init__(d_input=d_input, d_output=d_output, n_layers=n_layers, d_filter=d_filter, skip=skip,
+                         encoding=encoding)
+        self.base_log_temperature = base_log_temperature
+        self.base_log_density = base_log_density
+        self.log_absortpion = nn.ParameterDict([[str(w), torch.tensor(1.0e-6, dtype=torch.float32)]
+                                                for w in ops.AIA_WAVELENGTHS])
+        self.volumetric_constant = nn.Parameter(torch.tensor(1.0, dtype=torch.float32, requires_grad=True))
+
+    def log_abs_vector(self) -> torch.Tensor:
+        return torch.stack([self.log_absortpion[str(w)] for w in ops.AIA_WAVELENGTHS])
+
+    def forward(self, x: torch.Tensor):
+        from sunerf.rendering.functional import mlp_points
+        out = mlp_points(self, x)
+        out = torch.stack([out[:, 0] + self.base_log_density, out[:, 1] + self.base_log_temperature], -1)
+        return {'inferences': out, 'log_abs': self.log_absortpion, 'vol_c': self.volumetric_constant}

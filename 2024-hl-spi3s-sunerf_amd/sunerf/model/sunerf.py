@@ -12,6 +12,7 @@ from torch.optim.lr_scheduler import ExponentialLR
 
 from sunerf.rendering.base_tracing import SuNeRFRendering
 from sunerf.rendering.emission import EmissionRadiativeTransfer
+from sunerf.rendering.density_temperature import DensityTemperatureRadiativeTransfer
 from sunerf.train.scaling import ImageAsinhScaling
 
 try:  # pragma: no cover - depends on the environment
@@ -125,6 +126,54 @@ class EmissionSuNeRFModule(BaseSuNeRFModule):
             rays_o, rays_d = rays[:, 0].contiguous(), rays[:, 1].contiguous()
             with torch.no_grad():
                 outputs = self.rendering(rays_o, rays_d, time)
+            distance = rays_o.pow(2).sum(-1).pow(0.5)
+            return {'target_image': target_image, 'fine_image': outputs['fine_image'],
+                    'coarse_image': outputs['coarse_image'], 'height_map': outputs['height_map'],
+                    'absorption_map': outputs['absorption_map'], 'z_vals_stratified': outputs['z_vals_stratified'],
+                    'z_vals_hierarchical': outputs['z_vals_hierarchical'], 'distance': distance}
+
+
+class DensityTemperatureSuNeRFModule(BaseSuNeRFModule):
+    """sunerf.py:152-224."""
+
+    def __init__(self, Rs_per_ds, seconds_per_dt, image_scaling_config, model, loss=nn.MSELoss(), lambda_image=1.0,
+                 lambda_regularization=1.0, sampling_config=None, hierarchical_sampling_config=None,
+                 pixel_intensity_factor=1e17, model_config=None, **kwargs):
+        self.lambda_image = lambda_image
+        self.lambda_regularization = lambda_regularization
+        rendering_kwargs = {k: kwargs.pop(k) for k in ('response_table', 'response_path') if k in kwargs}
+        rendering = DensityTemperatureRadiativeTransfer(Rs_per_ds=Rs_per_ds, sampling_config=sampling_config,
+                                                        hierarchical_sampling_config=hierarchical_sampling_config,
+                                                        model_config=model_config, model=model,
+                                                        pixel_intensity_factor=pixel_intensity_factor, **rendering_kwargs)
+        super().__init__(Rs_per_ds=Rs_per_ds, seconds_per_dt=seconds_per_dt, rendering=rendering, **kwargs)
+        self.loss = loss
+
+    def training_step(self, batch, batch_nb):
+        tracing = batch['tracing']
+        rays, time, target_image, wavelengths = (tracing['rays'], tracing['time'], tracing['target_image'],
+                                                 tracing['wavelength'])
+        rays_o, rays_d = rays[:, 0].contiguous(), rays[:, 1].contiguous()
+        outputs = self.rendering.forward(rays_o, rays_d, time, wavelengths)
+        finite = torch.stack([torch.isfinite(v).all() for v in outputs.values()]).all()
+        assert bool(finite), '! [Numerical Alert] an output contains NaN or Inf.'
+        coarse_loss = self.loss(outputs['coarse_image'], target_image)
+        fine_loss = self.loss(outputs['fine_image'], target_image)
+        regularization_loss = outputs['regularization'].mean()
+        loss = (self.lambda_image * (coarse_loss + fine_loss) + self.lambda_regularization * regularization_loss)
+        with torch.no_grad():
+            psnr = -10. * torch.log10(fine_loss)
+        self.log('loss', loss)
+        self.log('train', {'coarse': coarse_loss, 'fine': fine_loss, 'regularization': regularization_loss, 'psnr': psnr})
+        return loss
+
+    def validation_step(self, batch, batch_nb, **kwargs):
+        dataloader_idx = kwargs['dataloader_idx'] if 'dataloader_idx' in kwargs else 0
+        if dataloader_idx == 0:
+            rays, time, target_image, wavelengths = batch['rays'], batch['time'], batch['target_image'], batch['wavelength']
+            rays_o, rays_d = rays[:, 0].contiguous(), rays[:, 1].contiguous()
+            with torch.no_grad():
+                outputs = self.rendering(rays_o, rays_d, time, wavelengths)
             distance = rays_o.pow(2).sum(-1).pow(0.5)
             return {'target_image': target_image, 'fine_image': outputs['fine_image'],
                     'coarse_image': outputs['coarse_image'], 'height_map': outputs['height_map'],

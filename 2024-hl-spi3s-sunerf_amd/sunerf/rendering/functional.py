@@ -76,3 +76,62 @@ def emission_pass(model, rays_o, rays_d, times, z_vals, reg_radius, want_epilogu
         return dict(zip(keys, outs))
     return ops.emission_render_fwd(model.packed(), rays_o, rays_d, times, z_vals, reg_radius,
                                    want_epilogues=want_epilogues)
+
+
+class _DtPass(torch.autograd.Function):
+    """One fused density/temperature pass: render kernel (MLP) -> DT integral kernel.  Differentiable outputs: ``image``
+    (N,W) and ``regularization``; gradients for the MLP parameters, the 7 ``log_absortpion`` scalars and
+    ``volumetric_constant``."""
+
+    @staticmethod
+    def forward(ctx, model, tables, pixel_factor, rays_o, rays_d, times, z_vals, wavelengths, reg_radius, want_epilogues,
+                vol_c, *params):
+        n_la = len(ops.AIA_WAVELENGTHS)
+        la = torch.stack([p.detach() for p in params[:n_la]])
+        training = any(ctx.needs_input_grad[10:])
+        packed = model.packed()
+        mlp = ops.emission_render_fwd(packed, rays_o, rays_d, times, z_vals, 0.0, want_raw=True, training=training)
+        out = ops.dt_integral_fwd(mlp['raw'], z_vals, rays_o, rays_d, wavelengths, tables[0], tables[1], la, vol_c,
+                                  model.base_log_density, model.base_log_temperature, pixel_factor, reg_radius,
+                                  want_epilogues=want_epilogues)
+        if training:
+            ctx.packed, ctx.tables, ctx.pixel_factor, ctx.reg_radius = packed, tables, pixel_factor, reg_radius
+            ctx.base = (model.base_log_density, model.base_log_temperature)
+            ctx.param_meta = [(p.shape, p.device) for p in params[n_la:]]
+            ctx.save_for_backward(rays_o, rays_d, z_vals, wavelengths, mlp['raw'], mlp['stash'], la, vol_c.detach())
+        outs = [out['image'], out['weights'], out['reg_q']]
+        non_diff = [out['weights'], out['reg_q']]
+        if want_epilogues:
+            outs += [out['height_map'], out['absorption_map'], out['regularization']]
+            non_diff += [out['height_map'], out['absorption_map']]
+        ctx.mark_non_differentiable(*non_diff)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_image, g_weights, g_q, g_hm=None, g_am=None, g_reg=None):
+        rays_o, rays_d, z_vals, wavelengths, raw, stash, la, vol_c = ctx.saved_tensors
+        if g_image is None:
+            g_image = torch.zeros(z_vals.shape[0], wavelengths.shape[1], dtype=torch.float32, device=z_vals.device)
+        g_raw, g_la, g_vc, absmax = ops.dt_integral_bwd(raw, z_vals, rays_o, rays_d, wavelengths, ctx.tables[0], ctx.tables[1],
+                                                        la, vol_c, ctx.base[0], ctx.base[1], ctx.pixel_factor, ctx.reg_radius,
+                                                        g_image.contiguous(), g_reg)
+        gW = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[0::2]]
+        gb = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[1::2]]
+        ops.mlp_backward(ctx.packed, g_raw, absmax, stash, gW, gb)
+        grads = []
+        for w, b in zip(gW, gb):
+            grads += [w, b]
+        return (None,) * 10 + (g_vc.reshape(()),) + tuple(g_la[i] for i in range(g_la.shape[0])) + tuple(grads)
+
+
+def dt_pass(model, tables, pixel_factor, rays_o, rays_d, times, z_vals, wavelengths, reg_radius, want_epilogues):
+    """Dict of one DT pass' outputs (image (N,W), weights, regularizing_quantity[, maps, regularization])."""
+    la = [model.log_absortpion[str(w)] for w in ops.AIA_WAVELENGTHS]
+    mlp_params = []
+    for lin in model.linears():
+        mlp_params += [lin.weight, lin.bias]
+    outs = _DtPass.apply(model, tables, pixel_factor, rays_o, rays_d, times, z_vals, wavelengths, reg_radius, want_epilogues,
+                         model.volumetric_constant, *la, *mlp_params)
+    keys = ['image', 'weights', 'regularizing_quantity'] + (['height_map', 'absorption_map', 'regularization']
+                                                            if want_epilogues else [])
+    return dict(zip(keys, outs))

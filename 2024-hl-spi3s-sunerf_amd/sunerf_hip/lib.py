@@ -44,6 +44,14 @@ _SIGNATURES = {
                                          ctypes.c_int64, ctypes.c_int, c_void, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
                                          c_void]),
+    'sunerf_dt_integral_fwd': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, c_f32p, c_f32p, c_f32p,
+                                               c_f32p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                               ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                               c_void]),
+    'sunerf_dt_integral_bwd': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, c_f32p, c_f32p, c_f32p,
+                                               c_f32p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                               ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_void,
+                                               c_void]),
     'sunerf_hier_resample': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                              ctypes.c_int, c_f32p, c_f32p, c_void]),
 }

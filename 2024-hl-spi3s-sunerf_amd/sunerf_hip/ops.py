@@ -194,6 +194,19 @@ def emission_render_bwd(packed: PackedMLP, rays_o, rays_d, z_vals, raw, stash, g
     st = lib.sunerf_emission_integral_bwd(_ptr(raw), _ptr(z_vals), _ptr(rays_o), _ptr(rays_d), _ptr(g_image), _ptr(g_reg),
                                           float(g_reg_const), float(reg_radius), n, s, _ptr(g_raw), _ptr(absmax), stream)
     _l.check(st, 'sunerf_emission_integral_bwd')
+    mlp_backward(packed, g_raw, absmax, stash, grad_weights, grad_biases, accumulate)
+    return g_raw
+
+
+def mlp_backward(packed: PackedMLP, g_raw, absmax, stash, grad_weights: Sequence[torch.Tensor],
+                 grad_biases: Sequence[torch.Tensor], accumulate: bool = False):
+    """dgrad + wgrad of the sine MLP from the gradient w.r.t. its raw output (N,S,2): fills / accumulates the nn.Linear
+    gradients.  ``absmax``: 4-byte device scalar with the bit pattern of max |g_raw| (written by the integral backward)."""
+    lib = _l.load()
+    n, s = g_raw.shape[0], g_raw.shape[1]
+    dev = g_raw.device
+    D, nl = packed.d_filter, packed.n_linear
+    stream = _stream(dev)
     dz = torch.empty(lib.sunerf_dz_stash_bytes(n, s, D, nl), dtype=torch.uint8, device=dev)
     st = lib.sunerf_mlp_dgrad(_ptr(packed.transposed()), D, nl, _ptr(g_raw), _ptr(absmax), _ptr(stash), _ptr(dz), n, s,
                               stream)
@@ -210,4 +223,60 @@ def emission_render_bwd(packed: PackedMLP, rays_o, rays_d, z_vals, raw, stash, g
     st = lib.sunerf_mlp_wgrad(D, nl, packed.d_out, _ptr(stash), _ptr(dz), _ptr(g_raw), _ptr(absmax), n, s, _ptr(ws),
                               split, GW, GB, int(accumulate), stream)
     _l.check(st, 'sunerf_mlp_wgrad')
-    return g_raw
+
+
+AIA_WAVELENGTHS = (94, 131, 171, 193, 211, 304, 335)
+
+
+def dt_integral_fwd(raw, z_vals, rays_o, rays_d, wavelengths, table_logt, table_resp, log_abs, vol_c, base_log_density,
+                    base_log_temperature, pixel_intensity_factor, reg_radius, want_epilogues=False):
+    """DT radiative-transfer integral on the raw MLP output (density_temperature.py:192-274)."""
+    lib = _l.load()
+    n, s = z_vals.shape
+    dev = z_vals.device
+    w = wavelengths.shape[1]
+    raw = _dev(raw, 'raw', (n, s, 2)); z_vals = _dev(z_vals, 'z_vals', (n, s))
+    rays_o = _dev(rays_o, 'rays_o', (n, 3)); rays_d = _dev(rays_d, 'rays_d', (n, 3))
+    wavelengths = _dev(wavelengths.to(torch.float32), 'wavelengths', (n, w))
+    table_logt = _dev(table_logt, 'table_logt', (7, 101)); table_resp = _dev(table_resp, 'table_resp', (7, 101))
+    log_abs = _dev(log_abs.detach(), 'log_abs', (7,)); vol_c = _dev(vol_c.detach().reshape(1), 'vol_c', (1,))
+    f32 = dict(dtype=torch.float32, device=dev)
+    out = {'image': torch.empty(n, w, **f32), 'weights': torch.empty(n, s, **f32), 'reg_q': torch.empty(n, s, **f32)}
+    hm = am = reg = None
+    if want_epilogues:
+        hm, am, reg = torch.empty(n, **f32), torch.empty(n, **f32), torch.empty(n, s, **f32)
+    st = lib.sunerf_dt_integral_fwd(_ptr(raw), _ptr(z_vals), _ptr(rays_o), _ptr(rays_d), _ptr(wavelengths), w,
+                                    _ptr(table_logt), _ptr(table_resp), _ptr(log_abs), _ptr(vol_c), float(base_log_density),
+                                    float(base_log_temperature), float(pixel_intensity_factor), float(reg_radius), n, s,
+                                    _ptr(out['image']), _ptr(out['weights']), _ptr(out['reg_q']), _ptr(hm), _ptr(am), _ptr(reg),
+                                    _stream(dev))
+    _l.check(st, 'sunerf_dt_integral_fwd')
+    if want_epilogues:
+        out.update(height_map=hm, absorption_map=am, regularization=reg)
+    return out
+
+
+def dt_integral_bwd(raw, z_vals, rays_o, rays_d, wavelengths, table_logt, table_resp, log_abs, vol_c, base_log_density,
+                    base_log_temperature, pixel_intensity_factor, reg_radius, g_image, g_reg):
+    """-> (g_raw (N,S,2), g_log_abs (7,), g_vol_c (1,), absmax)."""
+    lib = _l.load()
+    n, s = z_vals.shape
+    dev = z_vals.device
+    w = wavelengths.shape[1]
+    raw = _dev(raw, 'raw', (n, s, 2)); z_vals = _dev(z_vals, 'z_vals', (n, s))
+    rays_o = _dev(rays_o, 'rays_o', (n, 3)); rays_d = _dev(rays_d, 'rays_d', (n, 3))
+    wavelengths = _dev(wavelengths.to(torch.float32), 'wavelengths', (n, w))
+    log_abs = _dev(log_abs.detach(), 'log_abs', (7,)); vol_c = _dev(vol_c.detach().reshape(1), 'vol_c', (1,))
+    g_image = _dev(g_image, 'g_image', (n, w))
+    if g_reg is not None:
+        g_reg = _dev(g_reg, 'g_reg', (n, s))
+    f32 = dict(dtype=torch.float32, device=dev)
+    g_raw = torch.empty(n, s, 2, **f32)
+    g_la, g_vc = torch.empty(7, **f32), torch.empty(1, **f32)
+    absmax = torch.empty(1, dtype=torch.int32, device=dev)
+    st = lib.sunerf_dt_integral_bwd(_ptr(raw), _ptr(z_vals), _ptr(rays_o), _ptr(rays_d), _ptr(wavelengths), w,
+                                    _ptr(table_logt), _ptr(table_resp), _ptr(log_abs), _ptr(vol_c), float(base_log_density),
+                                    float(base_log_temperature), float(pixel_intensity_factor), float(reg_radius), n, s,
+                                    _ptr(g_image), _ptr(g_reg), _ptr(g_raw), _ptr(g_la), _ptr(g_vc), _ptr(absmax), _stream(dev))
+    _l.check(st, 'sunerf_dt_integral_bwd')
+    return g_raw, g_la, g_vc, absmax

@@ -135,6 +135,35 @@ int sunerf_mlp_wgrad(int d_filter, int n_linear, int d_out, const void* act_stas
                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Density / temperature head (run_density_temperature.py path).
+ * Replaces DensityTemperatureRadiativeTransfer.raw2outputs / regularization, density_temperature.py:192-274, the base
+ * offsets of NeRF_DT.forward, model.py:181-185, and the DT epilogues of base_tracing.py:99-110; the per-wavelength Python
+ * loop with host syncs (density_temperature.py:245-256) is one launch.  The MLP runs in sunerf_emission_render_fwd
+ * (its `raw` output is the input here; its emission outputs are ignored).
+ *
+ *   raw (N,S,2); wavelengths (N,W<=7) in Angstrom, <= 0 = channel absent; table_logt / table_resp (7,101) fp32 =
+ *   LOGTE / TRESP x exposure time of aia_temp_resp.genx in channel order 94,131,171,193,211,304,335
+ *   (density_temperature.py:131-146); log_abs (7) = log_absortpion parameters in that order; vol_c (1)
+ *   image (N,W); weights (N,S) = relu(inf0)/(sum+1e-10); reg_q (N,S) = relu(inf0);
+ *   height_map / absorption_map (N) and regularization (N,S) optional; reg_radius = 1.25 / Rs_per_ds
+ *   backward: g_image (N,W), g_reg (N,S) or NULL -> g_raw (N,S,2) (feed sunerf_mlp_dgrad / sunerf_mlp_wgrad),
+ *   g_log_abs (7), g_vol_c (1) (overwritten), g_absmax as in sunerf_emission_integral_bwd
+ * ---------------------------------------------------------------------------------------------------------- */
+int sunerf_dt_integral_fwd(const float* raw, const float* z_vals, const float* rays_o, const float* rays_d,
+                           const float* wavelengths, int n_wavelengths, const float* table_logt, const float* table_resp,
+                           const float* log_abs, const float* vol_c, float base_log_density, float base_log_temperature,
+                           float pixel_intensity_factor, float reg_radius, int64_t n_rays, int n_samples, float* image,
+                           float* weights, float* reg_q, float* height_map, float* absorption_map, float* regularization,
+                           void* stream);
+
+int sunerf_dt_integral_bwd(const float* raw, const float* z_vals, const float* rays_o, const float* rays_d,
+                           const float* wavelengths, int n_wavelengths, const float* table_logt, const float* table_resp,
+                           const float* log_abs, const float* vol_c, float base_log_density, float base_log_temperature,
+                           float pixel_intensity_factor, float reg_radius, int64_t n_rays, int n_samples,
+                           const float* g_image, const float* g_reg, float* g_raw, float* g_log_abs, float* g_vol_c,
+                           void* g_absmax, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Hierarchical (inverse-CDF) resampling + merge.
  * Replaces HierarchicalSampler.forward / sample_pdf, sampling.py:111-169 (perturb=False: u = linspace(0,1,S_f),
  * passed in as the tensor `u` [S_f] so that torch.linspace's own fp32 values are used; or a per-ray u [N,S_f]

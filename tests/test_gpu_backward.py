@@ -87,3 +87,21 @@ def test_backward_accumulates(ops):
     ops.emission_render_bwd(*args, accumulate=True)
     for a, b in zip(once, gW + gb):
         assert torch.allclose(b, 2 * a, rtol=1e-5, atol=1e-12)
+
+
+def test_backward_with_fewer_chunks_than_workgroups(ops):
+    """4 rays x 1 chunk: most wgrad workgroups have an empty slice and must not touch memory outside the stashes."""
+    params, o, d, t, z = _case(64, 8, 16, n_side=2)
+    g_image = torch.randn(o.shape[0]) * 1e-3
+    _, ref_grads, _ = _oracle_grads(params, o, d, t, z, g_image, 0.0)
+    dev = torch.device('cuda')
+    Ws = [W.to(dev) for W, _ in params]
+    bs = [b.to(dev) for _, b in params]
+    packed = ops.PackedMLP(Ws, bs)
+    fwd = ops.emission_render_fwd(packed, o.to(dev), d.to(dev), t.to(dev), z.to(dev), reg_radius=1.2, training=True)
+    gW = [torch.zeros_like(W) for W in Ws]
+    gb = [torch.zeros_like(b) for b in bs]
+    ops.emission_render_bwd(packed, o.to(dev), d.to(dev), z.to(dev), fwd['raw'], fwd['stash'], g_image.to(dev), None, 0.0, 1.2, gW, gb)
+    torch.cuda.synchronize()
+    for (rW, rb), W in zip(ref_grads, gW):
+        assert ((W.cpu() - rW).norm() / rW.norm()).item() < 2e-3
