@@ -84,10 +84,13 @@ __global__ __launch_bounds__(IB_THREADS) void integral_bwd_kernel(
 // ---------------------------------------------------------------------------------------------------------------
 // dgrad
 // ---------------------------------------------------------------------------------------------------------------
-// Transposed weight image "packedT" (pack_mlp_t_kernel), fp16, consumption order, 1 KiB per k-step (A fragment:
-// lane (m, h) element e = W_l[out feature kmapT][in feature 32U + m]):
-//   [out_layer^T : D/32 tiles x 1 k-step : K slot (h=0,e) = output e of the network (e < d_out), rest zero]
-//   for l = n_linear-2 down to 1: [W_l^T : D/32 tiles x D/16 k-steps, K order = kmap_hidden (fragment order of dZ_l)]
+// Transposed weight image "packedT" (pack_mlp_t_kernel), fp16, consumption order (A fragment: lane (m, h) element e =
+// W_l[out feature kmapT][in feature 32U + m]):
+//   [out_layer^T : D/32 tiles x 1 k-step x 1 KiB : K slot (h=0,e) = output e of the network (e < d_out), rest zero]
+//   for l = n_linear-2 down to 1: [W_l^T : D/32 tiles x D/16 k-steps x (hi 1 KiB | lo 1 KiB), K order = kmap_hidden]
+// The hidden weights are split hi + lo (two MFMAs per k-step): a single fp16 weight (2^-12 relative) is a SYSTEMATIC
+// error that every sample shares and that accumulates over the layers (measured 6e-4 on dW_0 of an 8-layer net);
+// the fp16 rounding of dZ itself is per-sample noise that averages out in the weight gradients.
 constexpr int DG_WAVES = 4;
 constexpr int DG_THREADS = DG_WAVES * 64;
 
@@ -111,12 +114,24 @@ __device__ __forceinline__ float gscale_from_bits(unsigned bits) {
   return ldexpf(1.f, 10 - e);
 }
 
+__device__ __forceinline__ void pin_agpr(half8& f) { asm volatile("" : "+a"(f)); }
+
+// dZ = dH * cos for one accumulator tile -> two fp16 fragments (the next layer's B operand and the dZ stash)
+__device__ __forceinline__ void dz_tile(const f32x16& acc, const half8& c0, const half8& c1, half8& d0, half8& d1) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    d0[j] = (_Float16)(acc[j] * (float)c0[j]);
+    d1[j] = (_Float16)(acc[8 + j] * (float)c1[j]);
+  }
+}
+
 template <int D>
 __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_kernel(DgradArgs a) {
   constexpr int NT = D / 32, KS = D / 16;
-  constexpr int BLK = KS * 1024;          // one (layer, tile) block of W^T: KS k-steps x 1 KiB
+  constexpr int BLK = KS * 2048;               // one (layer, tile) block of W^T: KS k-steps x (hi 1 KiB + lo 1 KiB)
   constexpr int VEC = BLK / 16 / DG_THREADS;   // 16-byte vectors per thread and block
-  static_assert(BLK % (16 * DG_THREADS) == 0, "block must split evenly over the threads");
+  constexpr int PD = 2;                        // weight blocks prefetched into registers (divides NT: static rotation)
+  static_assert(BLK % (16 * DG_THREADS) == 0 && NT % PD == 0, "block must split evenly over the threads");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x BLK
   const StashLayout SL(D, a.n_linear);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -125,9 +140,11 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_kernel(DgradArgs a) {
   const int n_chunks = (a.S + 31) >> 5;
   const int64_t n_groups = (a.n_rays + DG_WAVES - 1) / DG_WAVES;
   const float gscale = gscale_from_bits(*a.g_absmax_bits);
-  const char* wT_out = a.packedT;                               // NT x 1 KiB
+  const char* wT_out = a.packedT;                               // NT x 1 KiB (hi only: 2 output columns)
   const char* wT_hidden = a.packedT + (size_t)NT * 1024;        // (n_linear-2) layers x NT blocks, l descending
   const size_t dz_chunk_bytes = (size_t)n_act * KS * 1024;
+  const int n_hidden = a.n_linear - 2;
+  const int n_blocks = n_hidden * NT;
 
   for (int64_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
     const int64_t ray_raw = group * DG_WAVES + wave;
@@ -141,6 +158,27 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_kernel(DgradArgs a) {
       const char* sbase = a.stash + chunk_id * SL.chunk_bytes() + lane * 16;
       char* dzbase = a.dz_stash + chunk_id * dz_chunk_bytes + lane * 16;
 
+      // weight blocks 0..PD-1 of the chunk's stream -> registers (consumed through the LDS double buffer below)
+      f32x4 stage[PD][VEC];
+#pragma unroll
+      for (int p = 0; p < PD; ++p)
+        if (p < n_blocks) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v)
+            stage[p][v] = *(const f32x4*)(wT_hidden + (size_t)p * BLK + (size_t)(v * DG_THREADS + tid) * 16);
+        }
+      // cos fragments of the first two layers this chunk back-propagates through (one layer = 2*NT fragments ahead)
+      half8 ca[KS], cb[KS];
+      {
+        const char* c1 = sbase + SL.c_off(n_act - 1);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) ca[s] = *(const half8*)(c1 + s * 1024);
+        if (n_act >= 2) {
+          const char* c2 = sbase + SL.c_off(n_act - 2);
+#pragma unroll
+          for (int s = 0; s < KS; ++s) cb[s] = *(const half8*)(c2 + s * 1024);
+        }
+      }
       // dZ of the output layer as a B fragment: K slot 0 / 1 = d loss / d raw[..., 0 / 1]
       half8 dz_out = {0, 0, 0, 0, 0, 0, 0, 0};
       if (valid && h == 0) {
@@ -151,75 +189,104 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_kernel(DgradArgs a) {
       half8 xa[KS], xb[KS];
       // ---- out layer: dH_{L-1} = W_out^T dZ_out, one k-step per tile, A fragments straight from L2 ----
       {
-        const char* cbase = sbase + SL.c_off(n_act - 1);
         char* dzl = dzbase + (size_t)(n_act - 1) * KS * 1024;
 #pragma unroll
         for (int U = 0; U < NT; ++U) {
           const half8 aT = *(const half8*)(wT_out + U * 1024 + lane * 16);
           f32x16 acc = {0};
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aT, dz_out, acc, 0, 0, 0);
-          const half8 c0 = *(const half8*)(cbase + (2 * U) * 1024), c1 = *(const half8*)(cbase + (2 * U + 1) * 1024);
           half8 d0, d1;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { d0[j] = (_Float16)(acc[j] * (float)c0[j]); d1[j] = (_Float16)(acc[8 + j] * (float)c1[j]); }
+          dz_tile(acc, ca[2 * U], ca[2 * U + 1], d0, d1);
+          __builtin_nontemporal_store(d0, (half8*)(dzl + (2 * U) * 1024));
+          __builtin_nontemporal_store(d1, (half8*)(dzl + (2 * U + 1) * 1024));
+          pin_agpr(d0); pin_agpr(d1);
           xa[2 * U] = d0; xa[2 * U + 1] = d1;
-          *(half8*)(dzl + (2 * U) * 1024) = d0;
-          *(half8*)(dzl + (2 * U + 1) * 1024) = d1;
         }
       }
-      // ---- hidden layers, l = n_linear-2 ... 1 : dZ_{l-1} = (W_l^T dZ_l) * cos(Z_{l-1}) ----
-      // blocks are staged global -> registers -> LDS (double buffer) one block ahead by all 256 threads
-      const int n_hidden = a.n_linear - 2;
-      const int n_blocks = n_hidden * NT;
-      f32x4 stage[VEC];
-      if (n_blocks > 0) {
+      if (n_blocks > 0) {   // first block -> LDS buffer 0
+        __syncthreads();    // previous chunk's readers of buffer 0 are done
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) stage[v] = *(const f32x4*)(wT_hidden + (size_t)(v * DG_THREADS + tid) * 16);
-        __syncthreads();   // previous chunk's readers of buffer 0 are done
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) *(f32x4*)(smem + (size_t)(v * DG_THREADS + tid) * 16) = stage[v];
+        for (int v = 0; v < VEC; ++v) *(f32x4*)(smem + (size_t)(v * DG_THREADS + tid) * 16) = stage[0][v];
         __syncthreads();
       }
+      // ---- hidden layers, l = n_linear-2 ... 1 : dZ_{l-1} = (W_l^T dZ_l) * cos(Z_{l-1}) ----
+      // per tile: block blk is read from LDS buffer blk&1; block blk+1 (in registers since PD tiles) is written to the
+      // other buffer at the end of the tile; block blk+PD is requested from L2; the cos fragments of the layer AFTER
+      // the next one are requested one whole layer (2*NT fragments) ahead of their use.
       int blk = 0;
-      auto hidden_layer = [&](int l, const half8* x, half8* y) {   // consumes dZ_l (x), produces dZ_{l-1} (y)
-        const char* cbase = sbase + SL.c_off(l - 1);
+      // consumes dZ_l (x) and cos_{l-1} (cc), produces dZ_{l-1} (y); refills cc with cos_{l-3} for the layer after next
+      auto hidden_layer = [&](int l, const half8* x, half8* y, half8* cc) {
         char* dzl = dzbase + (size_t)(l - 1) * KS * 1024;
+        const bool more_cos = l - 3 >= 0;
+        const char* cnext = sbase + SL.c_off(more_cos ? l - 3 : 0);
 #pragma unroll
         for (int U = 0; U < NT; ++U) {
           const char* buf = smem + (blk & 1) * BLK;
-          const bool more = blk + 1 < n_blocks;
-          if (more) {
+          {
+            // unconditional (the last PD tiles of a chunk re-read the final block): a branch around these loads makes
+            // hipcc's s_waitcnt insertion fall back to a conservative count that drains the prefetches every tile
+            const int nb = min(blk + PD, n_blocks - 1);
 #pragma unroll
-            for (int v = 0; v < VEC; ++v)
-              stage[v] = *(const f32x4*)(wT_hidden + (size_t)(blk + 1) * BLK + (size_t)(v * DG_THREADS + tid) * 16);
+            for (int v = 0; v < VEC; ++v)   // block blk has left stage[U % PD] (written to LDS one tile ago)
+              stage[U % PD][v] = *(const f32x4*)(wT_hidden + (size_t)nb * BLK + (size_t)(v * DG_THREADS + tid) * 16);
           }
-          const half8 c0 = *(const half8*)(cbase + (2 * U) * 1024), c1 = *(const half8*)(cbase + (2 * U + 1) * 1024);
           f32x16 acc = {0};
+          {
+            // A fragments PF k-steps ahead of their MFMAs; sched_barrier pins the reads there (hipcc would otherwise sink
+            // each read next to its use and expose the LDS latency on every k-step)
+            constexpr int PF = KS < 4 ? KS : 4;
+            const char* fb = buf + lane * 16;
+            half8 fhi[PF], flo[PF];
 #pragma unroll
-          for (int s = 0; s < KS; ++s) {
-            const half8 aT = *(const half8*)(buf + s * 1024 + lane * 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aT, x[s], acc, 0, 0, 0);
+            for (int s = 0; s < PF; ++s) { fhi[s] = *(const half8*)(fb + s * 2048); flo[s] = *(const half8*)(fb + s * 2048 + 1024); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(flo[s % PF], x[s], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fhi[s % PF], x[s], acc, 0, 0, 0);
+              if (s + PF < KS) {
+                fhi[s % PF] = *(const half8*)(fb + (s + PF) * 2048);
+                flo[s % PF] = *(const half8*)(fb + (s + PF) * 2048 + 1024);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
           half8 d0, d1;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { d0[j] = (_Float16)(acc[j] * (float)c0[j]); d1[j] = (_Float16)(acc[8 + j] * (float)c1[j]); }
+          dz_tile(acc, cc[2 * U], cc[2 * U + 1], d0, d1);
+          // this tile's cos registers are free again: refill (unconditionally, see above; the last layers of a chunk
+          // re-read layer 0's fragments, which nobody consumes)
+          cc[2 * U] = *(const half8*)(cnext + (2 * U) * 1024);
+          cc[2 * U + 1] = *(const half8*)(cnext + (2 * U + 1) * 1024);
+          __builtin_nontemporal_store(d0, (half8*)(dzl + (2 * U) * 1024));
+          __builtin_nontemporal_store(d1, (half8*)(dzl + (2 * U + 1) * 1024));
+          pin_agpr(d0); pin_agpr(d1);
           y[2 * U] = d0; y[2 * U + 1] = d1;
-          *(half8*)(dzl + (2 * U) * 1024) = d0;
-          *(half8*)(dzl + (2 * U + 1) * 1024) = d1;
-          if (more) {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) *(f32x4*)(smem + ((blk + 1) & 1) * BLK + (size_t)(v * DG_THREADS + tid) * 16) = stage[v];
-          }
-          __syncthreads();
+          for (int v = 0; v < VEC; ++v)
+            *(f32x4*)(smem + ((blk + 1) & 1) * BLK + (size_t)(v * DG_THREADS + tid) * 16) = stage[(U + 1) % PD][v];
+          // LDS hand-off only: __syncthreads() would also drain every outstanding global load / store (vmcnt(0)) and
+          // with it the cos / weight prefetches that are meant to stay in flight across tiles
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
           ++blk;
         }
       };
+      // layer l uses cos_{l-1}: ca holds cos_{n_act-1} (used by the out layer) -> the first hidden layer l = n_act - 1
+      // uses cos_{n_act-2} = cb, the second ca (refilled with cos_{n_act-3} by the out layer below), and so on.
       int l = a.n_linear - 2;
-      for (; l - 1 >= 1; l -= 2) {
-        hidden_layer(l, xa, xb);
-        hidden_layer(l - 1, xb, xa);
+      if (l >= 1) {
+        // refill ca (free since the out layer) with the cos of the second hidden layer
+        if (l - 2 >= 0) {
+          const char* c3 = sbase + SL.c_off(l - 2);
+#pragma unroll
+          for (int s = 0; s < KS; ++s) ca[s] = *(const half8*)(c3 + s * 1024);
+        }
       }
-      if (l >= 1) hidden_layer(l, xa, xb);
+      for (; l - 1 >= 1; l -= 2) {
+        hidden_layer(l, xa, xb, cb);
+        hidden_layer(l - 1, xb, xa, ca);
+      }
+      if (l >= 1) hidden_layer(l, xa, xb, cb);
     }
   }
 }
@@ -234,7 +301,7 @@ struct PackTArgs {
 __global__ void pack_mlp_t_kernel(PackTArgs a) {
   const int NT = a.D / 32, KS = a.D / 16;
   const size_t n_out = (size_t)NT * 512;                               // halfs of the out^T part
-  const size_t n_hid = (size_t)(a.n_linear - 2) * NT * KS * 512;
+  const size_t n_hid = (size_t)(a.n_linear - 2) * NT * KS * 512;     // (hi, lo) pairs
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_out + n_hid) return;
   _Float16* dst = (_Float16*)a.packedT;
@@ -243,6 +310,8 @@ __global__ void pack_mlp_t_kernel(PackTArgs a) {
     const int U = (int)(idx / 512), lane = (int)(idx % 512) / 8, e = (int)(idx % 8);
     const int m = lane & 31, h = lane >> 5;
     if (h == 0 && e < a.d_out) w = a.W[a.n_linear - 1][(size_t)e * a.D + 32 * U + m];
+    dst[idx] = (_Float16)w;
+    return;
   } else {
     size_t r = idx - n_out;
     const int li = (int)(r / ((size_t)NT * KS * 512));   // 0 -> layer n_linear-2, 1 -> n_linear-3, ...
@@ -254,8 +323,12 @@ __global__ void pack_mlp_t_kernel(PackTArgs a) {
     const int m = lane & 31, h = lane >> 5;
     // A[m][k] = W_l^T[in = 32U+m][out = kmap_hidden(s,h,e)] = W_l[out][in]
     w = a.W[l][(size_t)kmap_hidden(s, h, e) * a.D + 32 * U + m];
+    const _Float16 hi = (_Float16)w;
+    const _Float16 lo = (_Float16)(w - (float)hi);
+    _Float16* blk = dst + n_out + ((size_t)li * NT + U) * KS * 1024;     // block of KS k-steps x 1024 halfs
+    blk[((size_t)(s * 2 + 0) * 64 + lane) * 8 + e] = hi;
+    blk[((size_t)(s * 2 + 1) * 64 + lane) * 8 + e] = lo;
   }
-  dst[idx] = (_Float16)w;
 }
 
 }  // namespace
@@ -263,7 +336,7 @@ __global__ void pack_mlp_t_kernel(PackTArgs a) {
 extern "C" size_t sunerf_packed_mlp_t_bytes(int d_filter, int n_linear) {
   if (d_filter <= 0 || d_filter % 32 || n_linear < 2 || n_linear > SUNERF_MAX_LAYERS) return 0;
   const size_t NT = d_filter / 32, KS = d_filter / 16;
-  return NT * 1024 + (size_t)(n_linear - 2) * NT * KS * 1024;
+  return NT * 1024 + (size_t)(n_linear - 2) * NT * KS * 2048;
 }
 
 extern "C" int sunerf_pack_mlp_t(const float* const* weights_host, int n_linear, int d_filter, int d_out, void* packedT,
@@ -277,7 +350,8 @@ extern "C" int sunerf_pack_mlp_t(const float* const* weights_host, int n_linear,
     a.W[i] = weights_host[i];
   }
   a.n_linear = n_linear; a.D = d_filter; a.d_out = d_out; a.packedT = (char*)packedT;
-  const size_t total = sunerf_packed_mlp_t_bytes(d_filter, n_linear) / 2;
+  const size_t NTh = d_filter / 32, KSh = d_filter / 16;
+  const size_t total = NTh * 512 + (size_t)(n_linear - 2) * NTh * KSh * 512;   // threads: out halfs + hidden (hi, lo) pairs
   const int threads = 256;
   SUNERF_CLEAR_ERROR();
   hipLaunchKernelGGL(pack_mlp_t_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0,
@@ -316,7 +390,7 @@ extern "C" int sunerf_emission_integral_bwd(const float* raw, const float* z_val
 
 template <int D>
 static int launch_dgrad(const DgradArgs& a, hipStream_t stream) {
-  const size_t lds = 2 * (size_t)(D / 16) * 1024;
+  const size_t lds = 2 * (size_t)(D / 16) * 2048;
   hipError_t e = hipFuncSetAttribute((const void*)dgrad_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   const int64_t n_groups = (a.n_rays + DG_WAVES - 1) / DG_WAVES;

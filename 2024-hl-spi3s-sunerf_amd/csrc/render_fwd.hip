@@ -226,11 +226,11 @@ __device__ __forceinline__ void epi_stage_c(const PairTmp& t, int p, half8& hi0,
   // (pinning after every insertion instead makes hipcc rewrite the whole 4-dword tuple each time: measured worse)
   if (p == 3) {
     pin_agpr(hi0); pin_agpr(lo0);
-    if (STASH) { *(half8*)st = hi0; *(half8*)(st + cos_delta) = ch0; }
+    if (STASH) { __builtin_nontemporal_store(hi0, (half8*)st); __builtin_nontemporal_store(ch0, (half8*)(st + cos_delta)); }
   }
   if (p == 7) {
     pin_agpr(hi1); pin_agpr(lo1);
-    if (STASH) { *(half8*)(st + 1024) = hi1; *(half8*)(st + 1024 + cos_delta) = ch1; }
+    if (STASH) { __builtin_nontemporal_store(hi1, (half8*)(st + 1024)); __builtin_nontemporal_store(ch1, (half8*)(st + 1024 + cos_delta)); }
   }
 }
 

@@ -103,10 +103,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # one rank per GPU; SUNERF_DIST_BACKEND=gloo + several ranks on one card is only for rehearsing the code path
+    local_dev = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('SUNERF_DIST_BACKEND', 'nccl')      # 'nccl' is RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from sunerf.model.model import NeRF
     from sunerf.rendering.functional import emission_pass
