@@ -157,7 +157,7 @@ def main():
         rays_per_step = B
         scaling = ImageAsinhScaling(vmax=1, a=0.005).to(dev)
         bucket = GradBucket(model.parameters())
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)      # one multi-tensor kernel (sunerf.py:31: Adam, lr 1e-4)
         tgt_scaled = scaling(target)
 
         def step(i):
