@@ -248,6 +248,7 @@ __global__ __launch_bounds__(DT_THREADS) void dt_integral_bwd_kernel(DtArgs a) {
 }
 
 int check_common(const DtArgs& a) {
+  if (a.n_rays == 0 && a.S >= 3 && a.W >= 1 && a.W <= NCH) return 0;
   if (!a.raw || !a.z_vals || !a.rays_o || !a.rays_d || !a.wavelengths || !a.table_logt || !a.table_resp || !a.log_abs || !a.vol_c)
     return SUNERF_E_BADARG;
   if (a.n_rays < 0 || a.S < 3) return SUNERF_E_BADARG;
@@ -270,8 +271,8 @@ extern "C" int sunerf_dt_integral_fwd(const float* raw, const float* z_vals, con
   a.S = n_samples; a.image = image; a.weights = weights; a.reg_q = reg_q; a.height_map = height_map;
   a.absorption_map = absorption_map; a.regularization = regularization;
   if (int rc = check_common(a)) return rc;
-  if (!image || !weights || !reg_q) return SUNERF_E_BADARG;
   if (n_rays == 0) return 0;
+  if (!image || !weights || !reg_q) return SUNERF_E_BADARG;
   SUNERF_CLEAR_ERROR();
   hipLaunchKernelGGL(dt_integral_fwd_kernel, dim3((unsigned)((n_rays + 7) / 8)), dim3(DT_THREADS), 0, (hipStream_t)stream, a);
   SUNERF_CHECK_LAUNCH();

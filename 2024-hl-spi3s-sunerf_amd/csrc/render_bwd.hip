@@ -369,8 +369,8 @@ extern "C" size_t sunerf_dz_stash_bytes(int64_t n_rays, int n_samples, int d_fil
 extern "C" int sunerf_emission_integral_bwd(const float* raw, const float* z_vals, const float* rays_o, const float* rays_d,
                                             const float* g_image, const float* g_reg, float g_reg_const, float reg_radius,
                                             int64_t n_rays, int n_samples, float* g_raw, void* g_absmax, void* stream) {
-  if (!raw || !z_vals || !rays_o || !rays_d || !g_image || !g_raw || !g_absmax) return SUNERF_E_BADARG;
-  if (n_rays < 0 || n_samples < 2) return SUNERF_E_BADARG;
+  if (n_rays < 0 || n_samples < 2 || !g_absmax) return SUNERF_E_BADARG;
+  if (n_rays > 0 && (!raw || !z_vals || !rays_o || !rays_d || !g_image || !g_raw)) return SUNERF_E_BADARG;
   const size_t lds = (size_t)n_samples * IB_THREADS * sizeof(float);
   if (lds > 160 * 1024) return SUNERF_E_UNSUPPORTED;
   hipError_t e = hipMemsetAsync(g_absmax, 0, 4, (hipStream_t)stream);
@@ -406,10 +406,10 @@ static int launch_dgrad(const DgradArgs& a, hipStream_t stream) {
 
 extern "C" int sunerf_mlp_dgrad(const void* packedT, int d_filter, int n_linear, const float* g_raw, const void* g_absmax,
                                 const void* act_stash, void* dz_stash, int64_t n_rays, int n_samples, void* stream) {
-  if (!packedT || !g_raw || !g_absmax || !act_stash || !dz_stash) return SUNERF_E_BADARG;
   if (n_rays < 0 || n_samples < 2) return SUNERF_E_BADARG;
   if (n_linear < 2 || n_linear > SUNERF_MAX_LAYERS) return SUNERF_E_UNSUPPORTED;
   if (n_rays == 0) return 0;
+  if (!packedT || !g_raw || !g_absmax || !act_stash || !dz_stash) return SUNERF_E_BADARG;
   DgradArgs a;
   a.packedT = (const char*)packedT; a.g_raw = g_raw; a.g_absmax_bits = (const unsigned*)g_absmax;
   a.stash = (const char*)act_stash; a.dz_stash = (char*)dz_stash; a.n_rays = n_rays; a.S = n_samples; a.n_linear = n_linear;

@@ -596,10 +596,10 @@ extern "C" int sunerf_emission_render_fwd(const void* packed, int d_filter, int 
                                           int64_t n_rays, int n_samples, float* image, float* weights,
                                           float* absorption, float* raw, float* height_map, float* absorption_map,
                                           float* regularization, float reg_radius, void* act_stash, void* stream) {
-  if (!packed || !rays_o || !rays_d || !times || !z_vals || !image || !weights || !absorption) return SUNERF_E_BADARG;
   if (n_rays < 0 || n_samples < 2) return SUNERF_E_BADARG;
   if (n_linear < 2 || n_linear > SUNERF_MAX_LAYERS) return SUNERF_E_UNSUPPORTED;
-  if (n_rays == 0) return 0;
+  if (n_rays == 0) return 0;      // an empty batch is valid (its tensors have null data pointers)
+  if (!packed || !rays_o || !rays_d || !times || !z_vals || !image || !weights || !absorption) return SUNERF_E_BADARG;
   RenderArgs a;
   a.packed = (const char*)packed; a.rays_o = rays_o; a.rays_d = rays_d; a.times = times; a.z_vals = z_vals;
   a.n_rays = n_rays; a.S = n_samples; a.n_linear = n_linear; a.image = image; a.weights = weights;

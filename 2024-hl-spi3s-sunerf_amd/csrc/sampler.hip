@@ -136,10 +136,10 @@ __global__ __launch_bounds__(RS_THREADS) void hier_resample_kernel(
 extern "C" int sunerf_sample_z(int sampler_kind, const float* rays_o, const float* rays_d, const float* t_vals,
                                const float* t_rand, int64_t n_rays, int n_samples, float distance, float solar_R,
                                float* z_vals, void* stream) {
-  if (!rays_o || !rays_d || !t_vals || !z_vals) return SUNERF_E_BADARG;
   if (n_rays < 0 || n_samples < 1) return SUNERF_E_BADARG;
   if (sampler_kind != SUNERF_SAMPLER_STRATIFIED && sampler_kind != SUNERF_SAMPLER_SPHERICAL) return SUNERF_E_UNSUPPORTED;
-  if (n_rays == 0) return 0;
+  if (n_rays == 0) return 0;      // an empty batch is valid (its tensors have null data pointers)
+  if (!rays_o || !rays_d || !t_vals || !z_vals) return SUNERF_E_BADARG;
   const int64_t total = n_rays * n_samples;
   const int threads = 256;
   const int64_t blocks = (total + threads - 1) / threads;
@@ -154,8 +154,9 @@ extern "C" int sunerf_sample_z(int sampler_kind, const float* rays_o, const floa
 extern "C" int sunerf_hier_resample(const float* z_vals, const float* weights, const float* u, int u_per_ray,
                                     int64_t n_rays, int n_coarse, int n_fine, float* new_z, float* z_comb,
                                     void* stream) {
-  if (!z_vals || !weights || !u || !new_z || !z_comb) return SUNERF_E_BADARG;
   if (n_rays < 0 || n_coarse < 3 || n_fine < 1) return SUNERF_E_BADARG;
+  if (n_rays == 0) return 0;
+  if (!z_vals || !weights || !u || !new_z || !z_comb) return SUNERF_E_BADARG;
   const size_t lds = ((size_t)2 * (n_coarse - 1) + n_fine) * RS_THREADS * sizeof(float);
   if (lds > 160 * 1024) return SUNERF_E_UNSUPPORTED;
   if (n_rays == 0) return 0;

@@ -290,8 +290,9 @@ extern "C" int sunerf_mlp_wgrad(int d_filter, int n_linear, int d_out, const voi
                                 const float* g_raw, const void* g_absmax, int64_t n_rays, int n_samples,
                                 void* workspace, int split, float* const* grad_weights_host,
                                 float* const* grad_biases_host, int accumulate, void* stream) {
-  if (!act_stash || !dz_stash || !g_raw || !g_absmax || !workspace || !grad_weights_host || !grad_biases_host) return SUNERF_E_BADARG;
+  if (!grad_weights_host || !grad_biases_host) return SUNERF_E_BADARG;
   if (n_rays < 0 || n_samples < 2 || split < 1) return SUNERF_E_BADARG;
+  if (n_rays > 0 && (!act_stash || !dz_stash || !g_raw || !g_absmax || !workspace)) return SUNERF_E_BADARG;
   if (n_linear < 2 || n_linear > SUNERF_MAX_LAYERS || d_out < 1 || d_out > 2) return SUNERF_E_UNSUPPORTED;
   if (d_filter != 64 && d_filter != 128 && d_filter != 256) return SUNERF_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;

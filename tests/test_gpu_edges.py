@@ -1,0 +1,88 @@
+"""Edge cases of the hot path on MI355X: empty batches, ragged sample counts, a single ray, rays that miss the sampling
+sphere (NaN z like the reference), large batches checked through size-independent properties."""
+import pytest
+import torch
+
+import sunerf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from sunerf_hip import ops as _ops
+    return _ops
+
+
+def _packed(ops, d_filter=64, n_layers=3, seed=5):
+    params = orc.init_params(d_filter=d_filter, n_layers=n_layers, seed=seed)
+    return params, ops.PackedMLP([W.cuda() for W, _ in params], [b.cuda() for _, b in params])
+
+
+def test_empty_batch(ops):
+    params, packed = _packed(ops)
+    o = torch.zeros(0, 3, device='cuda')
+    z = ops.sample_z(ops.SAMPLER_STRATIFIED, o, o, torch.linspace(0, 1, 32).cuda(), 1.3, 1.0)
+    assert z.shape == (0, 32)
+    out = ops.emission_render_fwd(packed, o, o, torch.zeros(0, device='cuda'), z, 1.2, want_epilogues=True, training=True)
+    assert out['image'].shape == (0, 1) and out['regularization'].shape == (0, 32)
+    nz, zc = ops.hier_resample(z, out['weights'], torch.linspace(0, 1, 16).cuda())
+    assert nz.shape == (0, 16) and zc.shape == (0, 48)
+    gW = [torch.ones_like(W).cuda() for W, _ in params]
+    gb = [torch.ones_like(b).cuda() for _, b in params]
+    ops.emission_render_bwd(packed, o, o, z, out['raw'], out['stash'], torch.zeros(0, device='cuda'), None, 0.0, 1.2, gW, gb)
+    assert all((g == 0).all() for g in gW + gb)          # an empty batch contributes a zero gradient
+
+
+@pytest.mark.parametrize('n_rays,S', [(1, 2), (1, 33), (3, 65), (5, 31), (7, 200)])
+def test_ragged_shapes_vs_oracle(ops, n_rays, S):
+    params, packed = _packed(ops)
+    torch.manual_seed(S)
+    o, d = orc.synthetic_rays(3)
+    o, d = o[:n_rays].contiguous(), d[:n_rays].contiguous()
+    t = torch.rand(n_rays, 1)
+    z = orc.stratified_z(o, d, orc.linspace_t_vals(S), torch.tensor(1.3), torch.tensor(1.0))
+    ref = orc.render_pass(params, o, d, t, z)
+    out = ops.emission_render_fwd(packed, o.cuda(), d.cuda(), t.cuda(), z.cuda(), 1.2, want_raw=True)
+    assert (out['raw'].cpu() - ref['raw']).abs().max().item() < 2e-5
+    assert ((out['image'].cpu() - ref['image']).abs().max() / ref['image'].abs().max()).item() < 1e-4
+    assert ((out['weights'].cpu() - ref['weights']).abs().max() / ref['weights'].abs().max()).item() < 1e-4
+
+
+def test_spherical_sampler_miss_gives_nan_like_reference(ops):
+    # a ray that misses the 2 Rs sphere: the reference's quadratic has no real root -> NaN z_vals (no guard, sampling.py:28-29)
+    o = torch.tensor([[0., 0., 215.]])
+    d = torch.tensor([[0.05, 0., -1.]])
+    d = d / d.norm()
+    z_ref = orc.spherical_z(o, d, orc.linspace_t_vals(8), torch.tensor(2.0), torch.tensor(1.0))
+    z = ops.sample_z(ops.SAMPLER_SPHERICAL, o.cuda(), d.cuda(), torch.linspace(0, 1, 8).cuda(), 2.0, 1.0).cpu()
+    assert torch.isnan(z_ref).all() and torch.isnan(z).all()
+
+
+def test_large_batch_properties(ops):
+    """BASELINE-sized launch (512 x 512 rays x 128 samples, 8 x 256 MLP): size-independent properties instead of a CPU
+    comparison -- weights of every ray sum to 1, absorption in (0, 1], the image equals the sum of the un-normalised
+    weights, identical rays give identical pixels, and a random subset matches the oracle."""
+    from sunerf_hip.rays import observer_rays
+    params, packed = _packed(ops, d_filter=256, n_layers=8, seed=7)
+    o, d = observer_rays(512, device='cuda')
+    n = o.shape[0]
+    t = torch.zeros(n, device='cuda')
+    z = ops.sample_z(ops.SAMPLER_STRATIFIED, o, d, torch.linspace(0, 1, 128).cuda(), 1.3, 1.0)
+    out = ops.emission_render_fwd(packed, o, d, t, z, 1.2, want_epilogues=True)
+    assert torch.isfinite(out['image']).all()
+    assert (out['weights'].sum(-1) - 1).abs().max().item() < 1e-4
+    assert (out['absorption'] > 0).all() and (out['absorption'] <= 1).all()
+    # the frame is mirror-symmetric in neither axis (theta, phi != 0), but re-rendering a permuted copy must permute pixels
+    perm = torch.randperm(n, device='cuda')[:4096]
+    out2 = ops.emission_render_fwd(packed, o[perm].contiguous(), d[perm].contiguous(), t[perm].contiguous(), z[perm].contiguous(), 1.2)
+    assert torch.equal(out2['image'], out['image'][perm])
+    idx = perm[:64].cpu()
+    ref = orc.render_pass(params, o.cpu()[idx], d.cpu()[idx], torch.zeros(64, 1), z.cpu()[idx])
+    assert ((out['image'].cpu()[idx] - ref['image']).abs().max() / ref['image'].abs().max()).item() < 1e-4
+
+
+def test_unsupported_width_is_a_clear_error():
+    from sunerf.model.model import NeRF
+    with pytest.raises(ValueError, match='d_filter'):
+        NeRF(d_filter=512)

@@ -34,7 +34,7 @@ def test_size_helpers(lib):
     steps = 8 * 6 + 7 * 8 * 16 + 16
     assert lib.sunerf_packed_mlp_bytes(256, 9) == steps * 2048 + (8 * 256 + 32) * 4
     assert lib.sunerf_packed_mlp_bytes(250, 9) == 0 and lib.sunerf_packed_mlp_bytes(256, 1) == 0
-    assert lib.sunerf_packed_mlp_t_bytes(256, 9) == 8 * 1024 + 7 * 8 * 16 * 1024
+    assert lib.sunerf_packed_mlp_t_bytes(256, 9) == 8 * 1024 + 7 * 8 * 16 * 2048     # out^T hi only; hidden hi + lo
     # stash: (6 enc + 8 layers x 2 x 16) fragments of 1 KiB per 32-sample chunk, + 1 spare chunk
     assert lib.sunerf_act_stash_bytes(10, 128, 256, 9) == (10 * 4 + 1) * (6 + 8 * 32) * 1024
     assert lib.sunerf_act_stash_bytes(10, 130, 256, 9) == (10 * 5 + 1) * (6 + 8 * 32) * 1024      # ragged last chunk
@@ -45,6 +45,8 @@ def test_size_helpers(lib):
 def test_argument_errors_without_gpu(lib):
     # null pointers / bad sizes are rejected before anything touches a device
     assert lib.sunerf_sample_z(0, None, None, None, None, 4, 8, 1.3, 1.0, None, None) == -1
+    assert lib.sunerf_sample_z(0, None, None, None, None, 0, 8, 1.3, 1.0, None, None) == 0       # empty batch: nothing to do
+    assert lib.sunerf_sample_z(7, None, None, None, None, 0, 8, 1.3, 1.0, None, None) == -2      # unknown sampler kind
     assert lib.sunerf_hier_resample(None, None, None, 0, 4, 8, 8, None, None, None) == -1
     assert lib.sunerf_emission_render_fwd(None, 256, 9, None, None, None, None, 4, 8, None, None, None, None, None, None,
                                           None, 1.2, None, None) == -1
