@@ -40,6 +40,7 @@ struct RenderArgs {
   float* regularization;
   float reg_radius;
   char* stash;
+  char* scratch;   // d_filter = 512: per-wave activation scratch, gridDim.x * 4 waves * (D/16) * 2 KiB
 };
 
 __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
@@ -111,7 +112,8 @@ __device__ __forceinline__ float shfl_up32(float v, int d, int n) {  // within t
 template <int D>
 struct Ring {
   static constexpr int KS = D / 16;
-  static constexpr int PAGE = KS * 2048;
+  static constexpr int PAGE_STEPS = KS < 16 ? KS : 16;   // k-steps per page (a d = 512 tile is two pages)
+  static constexpr int PAGE = PAGE_STEPS * 2048;
   static constexpr int RING = NSLOT * PAGE;
   static constexpr int PIECES = PAGE / 1024 / WAVES;     // 1 KiB DMA instructions per wave and page
   static_assert(NSLOT == 4 && PAGE % (1024 * WAVES) == 0, "page must split evenly over the waves");
@@ -211,10 +213,12 @@ __device__ __forceinline__ void epi_stage_b(PairTmp& t) {
   }
 }
 // `st`: this lane's address of the tile's first H fragment in the stash (training only); `cos_delta` = byte distance
-// from an H fragment to the matching cos fragment
-template <bool STASH>
+// from an H fragment to the matching cos fragment.  SPILL_OUT (d_filter = 512): the two activation sets do not fit the
+// register file together, so the finished hi / lo fragments go to this wave's global scratch at `sc`
+// ([fragment][hi 1 KiB | lo 1 KiB]) instead of staying in registers; they come back as the next layer's input.
+template <bool STASH, bool SPILL_OUT>
 __device__ __forceinline__ void epi_stage_c(const PairTmp& t, int p, half8& hi0, half8& lo0, half8& hi1, half8& lo1,
-                                            half8& ch0, half8& ch1, char* st, int cos_delta) {
+                                            half8& ch0, half8& ch1, char* st, int cos_delta, char* sc) {
   half2v lo;
   lo[0] = (_Float16)t.r0; lo[1] = (_Float16)t.r1;
   if (p < 4) { hi0[2 * p] = t.hi[0]; hi0[2 * p + 1] = t.hi[1]; lo0[2 * p] = lo[0]; lo0[2 * p + 1] = lo[1]; }
@@ -225,11 +229,13 @@ __device__ __forceinline__ void epi_stage_c(const PairTmp& t, int p, half8& hi0,
   }
   // (pinning after every insertion instead makes hipcc rewrite the whole 4-dword tuple each time: measured worse)
   if (p == 3) {
-    pin_agpr(hi0); pin_agpr(lo0);
+    if (SPILL_OUT) { *(half8*)sc = hi0; *(half8*)(sc + 1024) = lo0; }
+    else { pin_agpr(hi0); pin_agpr(lo0); }
     if (STASH) { __builtin_nontemporal_store(hi0, (half8*)st); __builtin_nontemporal_store(ch0, (half8*)(st + cos_delta)); }
   }
   if (p == 7) {
-    pin_agpr(hi1); pin_agpr(lo1);
+    if (SPILL_OUT) { *(half8*)(sc + 2048) = hi1; *(half8*)(sc + 3072) = lo1; }
+    else { pin_agpr(hi1); pin_agpr(lo1); }
     if (STASH) { __builtin_nontemporal_store(hi1, (half8*)(st + 1024)); __builtin_nontemporal_store(ch1, (half8*)(st + 1024 + cos_delta)); }
   }
 }
@@ -256,11 +262,12 @@ struct Mlp {
   static constexpr int KS = D / 16;
   static constexpr int XK = KS > SUNERF_KS0 ? KS : SUNERF_KS0;  // fragments per register set
   static constexpr int PF = 4;                                   // prefetch distance in k-steps
-  static constexpr int PAGE_STEPS = KS;                          // k-steps per DMA page
-  static constexpr int RING_STEPS = NSLOT * KS;
+  static constexpr int PAGE_STEPS = Ring<D>::PAGE_STEPS;         // k-steps per DMA page
+  static constexpr int RING_STEPS = NSLOT * PAGE_STEPS;
+  static constexpr bool SPILL = D > 256;   // one activation set in registers, layer outputs via global scratch
   static_assert(KS >= PF && SUNERF_KS0 >= PF, "prefetch distance exceeds a tile");
   static_assert((NT * SUNERF_KS0) % PF == 0 && KS % PF == 0, "fragment ring phase must be 0 at every layer start");
-  static_assert((NT * SUNERF_KS0) % KS == 0, "the in layer must end on a page boundary");
+  static_assert((NT * SUNERF_KS0) % PAGE_STEPS == 0 && KS % PAGE_STEPS == 0, "layers must end on page boundaries");
   // D >= 128: a hidden layer is a whole number of ring revolutions and a pass ends where it began, so the ring
   // position of every k-step is a compile-time constant (immediate ds_read offsets).  D = 64: tracked at run time.
   static constexpr bool STATIC_RING = (NT * KS) % RING_STEPS == 0 && (NT * SUNERF_KS0 + KS) % RING_STEPS == 0;
@@ -315,10 +322,13 @@ struct Mlp {
   // `prev`: accumulator of the previous tile whose epilogue is interleaved here (HAS_PREV), writing y*.
   // STASH (training): the epilogue also stores fp16 sin / cos fragments at `st` (4 stores of 1 KiB per tile); in a
   // steady-state page cycle those 4 stores are younger than the page being acquired, hence acquire<4>.
-  template <int KIN, int T0, bool HAS_PREV, int RS0, bool STASH>
-  static __device__ __forceinline__ f32x16 tile(Ring<D>& ring, Pipe& p, f32x16 acc, const half8* xhi, const half8* xlo,
+  // SPILL_OUT: the epilogue's fragments go to scratch at `sc_out` (see epi_stage_c).  RELOAD (last tile of a d = 512
+  // hidden layer): k-step s is the last reader of input fragment s, so it is refilled right there from `sc_in` with
+  // fragment s of the layer's OUTPUT (written to scratch at least one tile earlier) = the next layer's input.
+  template <int KIN, int T0, bool HAS_PREV, int RS0, bool STASH, bool SPILL_OUT = false, bool RELOAD = false>
+  static __device__ __forceinline__ f32x16 tile(Ring<D>& ring, Pipe& p, f32x16 acc, half8* xhi, half8* xlo,
                                                 const f32x16& prev, half8& yh0, half8& yl0, half8& yh1, half8& yl1,
-                                                char* st, int cos_delta) {
+                                                char* st, int cos_delta, char* sc_out = nullptr, const char* sc_in = nullptr) {
     // k-steps that carry epilogue micro-ops.  For the first tile of a layer the epilogue produces the layer's own last
     // two input fragments (read by k-steps KIN-2 and KIN-1), so it must be complete before k-step KIN-2.
     constexpr int EPI_STEPS = (KIN - 2) >= 8 ? 8 : (KIN - 2);
@@ -351,12 +361,20 @@ struct Mlp {
       if (HAS_PREV) {
 #pragma unroll
         for (int q = 0; q < PER; ++q)
-          if (s * PER + q < 8) epi_stage_c<STASH>(t[q], s * PER + q, yh0, yl0, yh1, yl1, ch0, ch1, st, cos_delta);
+          if (s * PER + q < 8) epi_stage_c<STASH, SPILL_OUT>(t[q], s * PER + q, yh0, yl0, yh1, yl1, ch0, ch1, st, cos_delta, sc_out);
+      }
+      if (RELOAD && s < KIN - 2) {   // fragments KIN-2, KIN-1 arrive through the carry epilogue of the next layer's first tile
+        xhi[s] = *(const half8*)(sc_in + s * 2048);
+        xlo[s] = *(const half8*)(sc_in + s * 2048 + 1024);
+        pin_agpr(xhi[s]); pin_agpr(xlo[s]);
       }
       {
         const int phase = (T0 + s) % PAGE_STEPS;
         if (phase == ACQ) {                                          // the reads below cross into the next page
-          if (STASH && HAS_PREV && KIN == KS) ring.template acquire<4>();
+          // vector-memory operations certainly issued after the last piece of the page being acquired (besides the
+          // pieces of the following page): the epilogue's stores, which fall into the first page cycle of a tile
+          constexpr int STORES = (HAS_PREV && KIN >= 16 && PER == 1) ? ((SPILL_OUT ? 4 : 0) + (STASH ? 4 : 0)) : 0;
+          if (s < 16) ring.template acquire<STORES>();
           else ring.template acquire<0>();
         }
         const int rel = (phase - ACQ - 1 + PAGE_STEPS) % PAGE_STEPS; // k-steps since the acquire, minus one
@@ -384,20 +402,32 @@ struct Mlp {
   // st_prev / st_own: this lane's stash address of fragment 0 of the previous / of this layer's H block (training).
   template <int KIN, bool HAS_CARRY, int RSL0, bool STASH>
   static __device__ __forceinline__ f32x16 layer(Ring<D>& ring, Pipe& p, const float* bias, int h, half8* xhi, half8* xlo,
-                                                 half8* yhi, half8* ylo, const f32x16& carry, char* st_prev, char* st_own) {
+                                                 half8* yhi, half8* ylo, const f32x16& carry, char* st_prev, char* st_own,
+                                                 char* scratch = nullptr) {
     f32x16 prev = carry;
     constexpr int CD = KS * 1024;
+    constexpr int XL = 2 * NT - 2;   // previous layer's last tile -> our X fragments
+    half8 th0, tl0, th1, tl1;        // SPILL: staging of the fragments that go to scratch
 #pragma unroll
     for (int U = 0; U < NT; ++U) {
       f32x16 acc = bias_tile(bias + 32 * U, h);
-      constexpr int XL = 2 * NT - 2;   // previous layer's last tile -> our X fragments
 #define SUNERF_TILE(UU)                                                                                          \
       if (U == UU) {                                                                                               \
         constexpr int RS = RSL0 < 0 ? -1 : (RSL0 + UU * KIN) % RING_STEPS;                                         \
-        if (UU == 0) acc = tile<KIN, (UU * KIN) % KS, HAS_CARRY, RS, STASH>(ring, p, acc, xhi, xlo, prev, xhi[XL], xlo[XL], xhi[XL + 1], xlo[XL + 1], st_prev + XL * 1024, CD); \
-        else acc = tile<KIN, (UU * KIN) % KS, true, RS, STASH>(ring, p, acc, xhi, xlo, prev, yhi[2 * UU - 2], ylo[2 * UU - 2], yhi[2 * UU - 1], ylo[2 * UU - 1], st_own + (2 * UU - 2) * 1024, CD); \
+        constexpr int T0 = (UU * KIN) % PAGE_STEPS;                                                               \
+        if constexpr (!SPILL) {                                                                                    \
+          if (UU == 0) acc = tile<KIN, T0, HAS_CARRY, RS, STASH>(ring, p, acc, xhi, xlo, prev, xhi[XL], xlo[XL], xhi[XL + 1], xlo[XL + 1], st_prev + XL * 1024, CD); \
+          else acc = tile<KIN, T0, true, RS, STASH>(ring, p, acc, xhi, xlo, prev, yhi[2 * UU - 2], ylo[2 * UU - 2], yhi[2 * UU - 1], ylo[2 * UU - 1], st_own + (2 * UU - 2) * 1024, CD); \
+        } else {                                                                                                   \
+          constexpr bool LAST = (UU == NT - 1) && (KIN == KS);                                                     \
+          if (UU == 0) acc = tile<KIN, T0, HAS_CARRY, RS, STASH, false, false>(ring, p, acc, xhi, xlo, prev, xhi[XL], xlo[XL], xhi[XL + 1], xlo[XL + 1], st_prev + XL * 1024, CD); \
+          else acc = tile<KIN, T0, true, RS, STASH, true, LAST>(ring, p, acc, xhi, xlo, prev, th0, tl0, th1, tl1, st_own + (2 * UU - 2) * 1024, CD, scratch + (2 * UU - 2) * 2048, scratch); \
+        }                                                                                                          \
       }
       SUNERF_TILE(0) SUNERF_TILE(1) SUNERF_TILE(2) SUNERF_TILE(3) SUNERF_TILE(4) SUNERF_TILE(5) SUNERF_TILE(6) SUNERF_TILE(7)
+      if constexpr (NT > 8) {
+        SUNERF_TILE(8) SUNERF_TILE(9) SUNERF_TILE(10) SUNERF_TILE(11) SUNERF_TILE(12) SUNERF_TILE(13) SUNERF_TILE(14) SUNERF_TILE(15)
+      }
 #undef SUNERF_TILE
       prev = acc;
     }
@@ -408,8 +438,8 @@ struct Mlp {
   static __device__ __forceinline__ f32x16 out_layer(Ring<D>& ring, Pipe& p, const float* bias, int h, half8* xhi,
                                                      half8* xlo, const f32x16& carry, char* st_prev) {
     constexpr int XL = 2 * NT - 2;
-    return tile<KS, 0, true, RS_HIDDEN, STASH>(ring, p, bias_tile(bias, h), xhi, xlo, carry, xhi[XL], xlo[XL], xhi[XL + 1],
-                                               xlo[XL + 1], st_prev + XL * 1024, KS * 1024);
+    return tile<KS, 0, true, RS_HIDDEN, STASH, false, false>(ring, p, bias_tile(bias, h), xhi, xlo, carry, xhi[XL], xlo[XL],
+                                                             xhi[XL + 1], xlo[XL + 1], st_prev + XL * 1024, KS * 1024);
   }
 };
 
@@ -461,16 +491,6 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
       const float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
       const float v[4] = {px, py, pz, tm};
 
-      half8 xa_hi[M::XK], xa_lo[M::XK], xb_hi[M::XK], xb_lo[M::XK];
-      {  // positional encoding straight into the in-layer B fragments (k-steps 0..5 of xb)
-        encode_point(v, h, [&](int q, float val) {
-          const _Float16 hi = (_Float16)val;
-          xb_hi[q >> 3][q & 7] = hi;
-          xb_lo[q >> 3][q & 7] = (_Float16)(val - (float)hi);
-        });
-#pragma unroll
-        for (int s = 0; s < SUNERF_KS0; ++s) { pin_agpr(xb_hi[s]); pin_agpr(xb_lo[s]); }
-      }
       // training: this chunk's slice of the activation stash (lane-adjusted); enc fragments first
       char* sbase = nullptr;
       if (STASH) {
@@ -478,30 +498,73 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
         const size_t chunk_id = ray_ok ? (size_t)ray_raw * n_chunks + c : (size_t)a.n_rays * n_chunks;
         sbase = a.stash + chunk_id * SL.chunk_bytes() + lane * 16;
       }
-      if (STASH) {
-#pragma unroll
-        for (int s = 0; s < SUNERF_KS0; ++s) *(half8*)(sbase + s * 1024) = xb_hi[s];
-      }
-      // in layer: 84(96) -> D
-      f32x16 carry = {0};
-      carry = M::template layer<SUNERF_KS0, false, M::RS_IN, STASH>(ring, pipe, bias, h, xb_hi, xb_lo, xa_hi, xa_lo, carry,
-                                                                    nullptr, sbase + SL.h_off(0));
-      // hidden layers, ping-pong between the two register sets
-      int l = 1;
-      for (; l + 1 < a.n_linear - 1; l += 2) {
-        carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)l * D, h, xa_hi, xa_lo, xb_hi, xb_lo,
-                                                                    carry, sbase + SL.h_off(l - 1), sbase + SL.h_off(l));
-        carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)(l + 1) * D, h, xb_hi, xb_lo, xa_hi,
-                                                                    xa_lo, carry, sbase + SL.h_off(l), sbase + SL.h_off(l + 1));
-      }
       f32x16 out;
       const float* obias = bias + (size_t)(a.n_linear - 1) * D;
-      if (l < a.n_linear - 1) {
-        carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)l * D, h, xa_hi, xa_lo, xb_hi, xb_lo,
-                                                                    carry, sbase + SL.h_off(l - 1), sbase + SL.h_off(l));
-        out = M::template out_layer<STASH>(ring, pipe, obias, h, xb_hi, xb_lo, carry, sbase + SL.h_off(l));
+      if constexpr (!M::SPILL) {
+        half8 xa_hi[M::XK], xa_lo[M::XK], xb_hi[M::XK], xb_lo[M::XK];
+        {  // positional encoding straight into the in-layer B fragments (k-steps 0..5 of xb)
+          encode_point(v, h, [&](int q, float val) {
+            const _Float16 hi = (_Float16)val;
+            xb_hi[q >> 3][q & 7] = hi;
+            xb_lo[q >> 3][q & 7] = (_Float16)(val - (float)hi);
+          });
+#pragma unroll
+          for (int s = 0; s < SUNERF_KS0; ++s) { pin_agpr(xb_hi[s]); pin_agpr(xb_lo[s]); }
+        }
+        if (STASH) {
+#pragma unroll
+          for (int s = 0; s < SUNERF_KS0; ++s) *(half8*)(sbase + s * 1024) = xb_hi[s];
+        }
+        // in layer: 84(96) -> D
+        f32x16 carry = {0};
+        carry = M::template layer<SUNERF_KS0, false, M::RS_IN, STASH>(ring, pipe, bias, h, xb_hi, xb_lo, xa_hi, xa_lo, carry,
+                                                                      nullptr, sbase + SL.h_off(0));
+        // hidden layers, ping-pong between the two register sets
+        int l = 1;
+        for (; l + 1 < a.n_linear - 1; l += 2) {
+          carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)l * D, h, xa_hi, xa_lo, xb_hi, xb_lo,
+                                                                      carry, sbase + SL.h_off(l - 1), sbase + SL.h_off(l));
+          carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)(l + 1) * D, h, xb_hi, xb_lo, xa_hi,
+                                                                      xa_lo, carry, sbase + SL.h_off(l), sbase + SL.h_off(l + 1));
+        }
+        if (l < a.n_linear - 1) {
+          carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)l * D, h, xa_hi, xa_lo, xb_hi, xb_lo,
+                                                                      carry, sbase + SL.h_off(l - 1), sbase + SL.h_off(l));
+          out = M::template out_layer<STASH>(ring, pipe, obias, h, xb_hi, xb_lo, carry, sbase + SL.h_off(l));
+        } else {
+          out = M::template out_layer<STASH>(ring, pipe, obias, h, xa_hi, xa_lo, carry, sbase + SL.h_off(l - 1));
+        }
       } else {
-        out = M::template out_layer<STASH>(ring, pipe, obias, h, xa_hi, xa_lo, carry, sbase + SL.h_off(l - 1));
+        // d_filter = 512: ONE activation set in registers (256 AGPRs); every layer writes its output fragments to this
+        // wave's scratch and the last tile of the layer pulls them back in as the next layer's input
+        char* scratch = a.scratch + ((size_t)blockIdx.x * WAVES + wave) * ((size_t)M::KS * 2048) + lane * 16;
+        half8 x_hi[M::KS], x_lo[M::KS];
+        encode_point(v, h, [&](int q, float val) {
+          const _Float16 hi = (_Float16)val;
+          x_hi[q >> 3][q & 7] = hi;
+          x_lo[q >> 3][q & 7] = (_Float16)(val - (float)hi);
+        });
+#pragma unroll
+        for (int s = 0; s < SUNERF_KS0; ++s) { pin_agpr(x_hi[s]); pin_agpr(x_lo[s]); }
+        if (STASH) {
+#pragma unroll
+          for (int s = 0; s < SUNERF_KS0; ++s) *(half8*)(sbase + s * 1024) = x_hi[s];
+        }
+        f32x16 carry = {0};
+        carry = M::template layer<SUNERF_KS0, false, M::RS_IN, STASH>(ring, pipe, bias, h, x_hi, x_lo, nullptr, nullptr, carry,
+                                                                      nullptr, sbase + SL.h_off(0), scratch);
+        // the in layer's tiles are too short to pull the next input in one by one: fetch fragments 0 .. KS-3 now (the
+        // last two arrive through the carry epilogue)
+#pragma unroll
+        for (int s = 0; s < M::KS - 2; ++s) {
+          x_hi[s] = *(const half8*)(scratch + s * 2048);
+          x_lo[s] = *(const half8*)(scratch + s * 2048 + 1024);
+          pin_agpr(x_hi[s]); pin_agpr(x_lo[s]);
+        }
+        for (int l = 1; l < a.n_linear - 1; ++l)
+          carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)l * D, h, x_hi, x_lo, nullptr, nullptr,
+                                                                      carry, sbase + SL.h_off(l - 1), sbase + SL.h_off(l), scratch);
+        out = M::template out_layer<STASH>(ring, pipe, obias, h, x_hi, x_lo, carry, sbase + SL.h_off(a.n_linear - 2));
       }
 
       // ---- emission / absorption integral for this chunk (emission.py:14-54); lanes 0..31 hold rows 0,1 ----
@@ -572,6 +635,7 @@ int launch_render_t(const RenderArgs& a, hipStream_t stream) {
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (cus > 1024) cus = 1024;   // sunerf_render_workspace_bytes is sized for at most 1024 workgroups
   const unsigned grid = (unsigned)(n_groups < cus ? n_groups : cus);
   SUNERF_CLEAR_ERROR();
   hipLaunchKernelGGL((render_fwd_kernel<D, STASH>), dim3(grid), dim3(THREADS), lds, stream, a);
@@ -585,6 +649,12 @@ int launch_render(const RenderArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+// d_filter = 512 keeps one activation set in registers and spills layer outputs to a per-wave scratch: at most 256
+// workgroups (one per CU) x 4 waves x (D/16) fragments x 2 KiB
+extern "C" size_t sunerf_render_workspace_bytes(int d_filter) {
+  return d_filter > 256 ? (size_t)1024 * 4 * (size_t)(d_filter / 16) * 2048 : 0;
+}
+
 extern "C" size_t sunerf_act_stash_bytes(int64_t n_rays, int n_samples, int d_filter, int n_linear) {
   if (n_rays < 0 || n_samples < 1 || d_filter < 32 || d_filter % 32 || n_linear < 2) return 0;
   const int64_t chunks = n_rays * ((n_samples + 31) / 32) + 1;   // + one spare chunk for ragged groups
@@ -595,7 +665,8 @@ extern "C" int sunerf_emission_render_fwd(const void* packed, int d_filter, int 
                                           const float* rays_d, const float* times, const float* z_vals,
                                           int64_t n_rays, int n_samples, float* image, float* weights,
                                           float* absorption, float* raw, float* height_map, float* absorption_map,
-                                          float* regularization, float reg_radius, void* act_stash, void* stream) {
+                                          float* regularization, float reg_radius, void* act_stash, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
   if (n_rays < 0 || n_samples < 2) return SUNERF_E_BADARG;
   if (n_linear < 2 || n_linear > SUNERF_MAX_LAYERS) return SUNERF_E_UNSUPPORTED;
   if (n_rays == 0) return 0;      // an empty batch is valid (its tensors have null data pointers)
@@ -605,10 +676,13 @@ extern "C" int sunerf_emission_render_fwd(const void* packed, int d_filter, int 
   a.n_rays = n_rays; a.S = n_samples; a.n_linear = n_linear; a.image = image; a.weights = weights;
   a.absorption = absorption; a.raw = raw; a.height_map = height_map; a.absorption_map = absorption_map;
   a.regularization = regularization; a.reg_radius = reg_radius; a.stash = (char*)act_stash;
+  a.scratch = (char*)workspace;
+  if (workspace_bytes < sunerf_render_workspace_bytes(d_filter)) return SUNERF_E_WORKSPACE;
   switch (d_filter) {
     case 64: return launch_render<64>(a, (hipStream_t)stream);
     case 128: return launch_render<128>(a, (hipStream_t)stream);
     case 256: return launch_render<256>(a, (hipStream_t)stream);
+    case 512: return launch_render<512>(a, (hipStream_t)stream);
     default: return SUNERF_E_UNSUPPORTED;
   }
 }

@@ -28,9 +28,11 @@ _SIGNATURES = {
     'sunerf_sample_z': (ctypes.c_int, [ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int64, ctypes.c_int,
                                         ctypes.c_float, ctypes.c_float, c_f32p, c_void]),
     'sunerf_act_stash_bytes': (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    'sunerf_render_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int]),
     'sunerf_emission_render_fwd': (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p,
                                                    ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p,
-                                                   c_f32p, c_f32p, c_f32p, ctypes.c_float, c_void, c_void]),
+                                                   c_f32p, c_f32p, c_f32p, ctypes.c_float, c_void, c_void, ctypes.c_size_t,
+                                                   c_void]),
     'sunerf_packed_mlp_t_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     'sunerf_pack_mlp_t': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           c_void, c_void]),

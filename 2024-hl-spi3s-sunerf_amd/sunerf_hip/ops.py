@@ -12,7 +12,9 @@ from . import lib as _l
 
 SAMPLER_STRATIFIED = 0
 SAMPLER_SPHERICAL = 1
-SUPPORTED_D_FILTER = (64, 128, 256)
+SUPPORTED_D_FILTER = (64, 128, 256, 512)
+TRAINABLE_D_FILTER = (64, 128, 256)     # the backward kernels do not cover the 512-wide net yet
+_workspaces = {}                        # device -> scratch for the d_filter = 512 render kernel (per stream use is serial)
 
 
 def _dev(t: torch.Tensor, name: str, shape=None) -> torch.Tensor:
@@ -126,6 +128,16 @@ def emission_render_fwd(packed: PackedMLP, rays_o, rays_d, times, z_vals, reg_ra
     out = {'image': torch.empty(n, 1, **f32), 'weights': torch.empty(n, s, **f32),
            'absorption': torch.empty(n, s, **f32)}
     want_raw = want_raw or training
+    if training and packed.d_filter not in TRAINABLE_D_FILTER:
+        raise NotImplementedError(f'training with d_filter={packed.d_filter} is not implemented (inference only); '
+                                  f'trainable widths: {TRAINABLE_D_FILTER}')
+    ws_bytes = lib.sunerf_render_workspace_bytes(packed.d_filter)
+    ws = None
+    if ws_bytes:
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+        ws = _workspaces.get(key)
+        if ws is None or ws.numel() < ws_bytes:
+            ws = _workspaces[key] = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     raw = torch.empty(n, s, 2, **f32) if want_raw else None
     stash = None
     if training:
@@ -137,7 +149,7 @@ def emission_render_fwd(packed: PackedMLP, rays_o, rays_d, times, z_vals, reg_ra
     st = lib.sunerf_emission_render_fwd(_ptr(packed.buffer), packed.d_filter, packed.n_linear, _ptr(rays_o),
                                         _ptr(rays_d), _ptr(times), _ptr(z_vals), n, s, _ptr(out['image']),
                                         _ptr(out['weights']), _ptr(out['absorption']), _ptr(raw), _ptr(hm), _ptr(am),
-                                        _ptr(reg), float(reg_radius), _ptr(stash), _stream(dev))
+                                        _ptr(reg), float(reg_radius), _ptr(stash), _ptr(ws), ws_bytes, _stream(dev))
     _l.check(st, 'sunerf_emission_render_fwd')
     if want_raw:
         out['raw'] = raw

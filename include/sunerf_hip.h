@@ -87,16 +87,20 @@ int sunerf_sample_z(int sampler_kind, const float* rays_o, const float* rays_d, 
  *   height_map, absorption_map : [N] or NULL;  regularization : [N,S] or NULL  (base_tracing.py:99-106)
  *   reg_radius : 1.2 / Rs_per_ds (base_tracing.py:44)
  *   act_stash  : NULL for inference; for training a device buffer of sunerf_act_stash_bytes() bytes that
- *                receives the hidden activations for sunerf_emission_render_bwd
+ *                receives the hidden activations for the backward kernels
+ *   workspace  : sunerf_render_workspace_bytes(d_filter) bytes of device scratch (may be NULL when that is 0)
  * ---------------------------------------------------------------------------------------------------------- */
 size_t sunerf_act_stash_bytes(int64_t n_rays, int n_samples, int d_filter, int n_linear);
+/* d_filter = 512 (the reference's default width, model.py:16): scratch for layer outputs; 0 for narrower nets */
+size_t sunerf_render_workspace_bytes(int d_filter);
 
 int sunerf_emission_render_fwd(const void* packed, int d_filter, int n_linear,
                                const float* rays_o, const float* rays_d, const float* times,
                                const float* z_vals, int64_t n_rays, int n_samples,
                                float* image, float* weights, float* absorption, float* raw,
                                float* height_map, float* absorption_map, float* regularization,
-                               float reg_radius, void* act_stash, void* stream);
+                               float reg_radius, void* act_stash, void* workspace, size_t workspace_bytes,
+                               void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Backward of the fused render pass (training).  The reference has no backward code of its own: these entry points

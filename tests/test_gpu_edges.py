@@ -85,4 +85,19 @@ def test_large_batch_properties(ops):
 def test_unsupported_width_is_a_clear_error():
     from sunerf.model.model import NeRF
     with pytest.raises(ValueError, match='d_filter'):
-        NeRF(d_filter=512)
+        NeRF(d_filter=384)
+
+
+@pytest.mark.parametrize('n_layers,S', [(8, 64), (2, 32), (3, 40)])
+def test_reference_default_width_512_forward(ops, n_layers, S):
+    """d_filter = 512 is the reference's default (model.py:16): one activation set in registers + scratch spill."""
+    params, packed = _packed(ops, d_filter=512, n_layers=n_layers, seed=11)
+    torch.manual_seed(S)
+    o, d = orc.synthetic_rays(5)
+    t = torch.rand(o.shape[0], 1) * 3
+    z = orc.stratified_z(o, d, orc.linspace_t_vals(S), torch.tensor(1.3), torch.tensor(1.0))
+    ref = orc.render_pass(params, o, d, t, z)
+    out = ops.emission_render_fwd(packed, o.cuda(), d.cuda(), t.cuda(), z.cuda(), 1.2, want_raw=True)
+    assert (out['raw'].cpu() - ref['raw']).abs().max().item() < 2e-5
+    assert ((out['image'].cpu() - ref['image']).abs().max() / ref['image'].abs().max()).item() < 1e-4
+    assert ((out['weights'].cpu() - ref['weights']).abs().max() / ref['weights'].abs().max()).item() < 1e-4
