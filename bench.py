@@ -31,7 +31,12 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 D_FILTER, N_LAYERS, ENC = 256, 8, 84
-FLOPS_FWD_PER_SAMPLE = 2 * (ENC * D_FILTER + (N_LAYERS - 1) * D_FILTER * D_FILTER + D_FILTER * 2)   # 961 536
+def flops_fwd(d):
+    return 2 * (ENC * d + (N_LAYERS - 1) * d * d + d * 2)            # 961 536 at d = 256
+
+
+def flops_bwd(d):
+    return 2 * ((N_LAYERS - 1) * d * d + d * 2) + flops_fwd(d)        # dgrad + wgrad = 1 880 064 at d = 256
 PEAK_F16_DENSE_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense BF16/F16 MFMA peak
 PEAK_F32_MFMA_TFLOPS = 157.3
 
@@ -83,8 +88,6 @@ def cpu_baseline(res, samples, mode, seconds_budget=20.0):
                       + f', best of {reps}'}
 
 
-FLOPS_BWD_PER_SAMPLE = 2 * ((N_LAYERS - 1) * D_FILTER * D_FILTER + D_FILTER * 2) \
-    + 2 * (ENC * D_FILTER + (N_LAYERS - 1) * D_FILTER * D_FILTER + D_FILTER * 2)          # dgrad + wgrad = 1 880 064
 
 
 def main():
@@ -97,7 +100,9 @@ def main():
     ap.add_argument('--batch', type=int, default=32768, help='rays per rank and optimiser step (train mode)')
     ap.add_argument('--mode', choices=['train', 'fwd'], default='train')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--d-filter', type=int, default=D_FILTER, help='MLP width (headline: 256; 512 = reference default, fwd only)')
     args = ap.parse_args()
+    globals()['D_FILTER'] = args.d_filter
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -141,7 +146,7 @@ def main():
 
         def step(i):
             return ops.emission_render_fwd(packed, rays_o, rays_d, times, z_vals, reg_radius=1.2, want_epilogues=True)['image']
-        flops_per_sample, kernel_name = FLOPS_FWD_PER_SAMPLE, 'render_fwd_kernel<256, false>'
+        flops_per_sample, kernel_name = flops_fwd(D_FILTER), f'render_fwd_kernel<{D_FILTER}, false>'
     else:
         # this rank's rows of the frame; batches of --batch rays cycle through them
         r0, r1 = shard_range(args.res, rank, world)
@@ -172,7 +177,7 @@ def main():
             bucket.clip_grad_norm_(0.5)
             opt.step()
             return loss
-        flops_per_sample, kernel_name = FLOPS_FWD_PER_SAMPLE + FLOPS_BWD_PER_SAMPLE, 'render_fwd_kernel<256, true> + dgrad + wgrad'
+        flops_per_sample, kernel_name = flops_fwd(D_FILTER) + flops_bwd(D_FILTER), f'render_fwd_kernel<{D_FILTER}, true> + dgrad + wgrad'
 
     for i in range(args.warmup):
         step(i)
