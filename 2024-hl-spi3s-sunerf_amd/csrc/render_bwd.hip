@@ -128,10 +128,17 @@ __device__ __forceinline__ void dz_tile(const f32x16& acc, const half8& c0, cons
 template <int D>
 __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_kernel(DgradArgs a) {
   constexpr int NT = D / 32, KS = D / 16;
-  constexpr int BLK = KS * 2048;               // one (layer, tile) block of W^T: KS k-steps x (hi 1 KiB + lo 1 KiB)
+  constexpr int HB = KS < 16 ? KS : 16;        // k-steps per staged weight block
+  constexpr int NB = KS / HB;                  // blocks per (layer, tile): 2 at D = 512 (a 64 KiB tile would not double-buffer)
+  constexpr int BLK = HB * 2048;               // one block of W^T: HB k-steps x (hi 1 KiB + lo 1 KiB)
   constexpr int VEC = BLK / 16 / DG_THREADS;   // 16-byte vectors per thread and block
-  constexpr int PD = 2;                        // weight blocks prefetched into registers (divides NT: static rotation)
-  static_assert(BLK % (16 * DG_THREADS) == 0 && NT % PD == 0, "block must split evenly over the threads");
+  constexpr int PD = 2;                        // weight blocks prefetched into registers (divides NT * NB: static rotation)
+  // cos fragments: D <= 256 keeps two whole layers in registers (ca / cb alternate); D = 512 keeps ONE sliding window of
+  // CW tiles (a layer is 128 registers there), refilled CW tiles ahead across the layer boundary
+  constexpr bool WINDOW = D > 256;
+  constexpr int CW = 8;
+  static_assert(BLK % (16 * DG_THREADS) == 0 && (NT * NB) % PD == 0, "block must split evenly over the threads");
+  static_assert(!WINDOW || (NT % CW == 0 && NB == PD), "window / stage rotation must be static");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x BLK
   const StashLayout SL(D, a.n_linear);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_kernel(DgradArgs a) {
   const char* wT_hidden = a.packedT + (size_t)NT * 1024;        // (n_linear-2) layers x NT blocks, l descending
   const size_t dz_chunk_bytes = (size_t)n_act * KS * 1024;
   const int n_hidden = a.n_linear - 2;
-  const int n_blocks = n_hidden * NT;
+  const int n_blocks = n_hidden * NT * NB;
 
   for (int64_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
     const int64_t ray_raw = group * DG_WAVES + wave;
@@ -168,17 +175,26 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_kernel(DgradArgs a) {
             stage[p][v] = *(const f32x4*)(wT_hidden + (size_t)p * BLK + (size_t)(v * DG_THREADS + tid) * 16);
         }
       // cos fragments of the first two layers this chunk back-propagates through (one layer = 2*NT fragments ahead)
-      half8 ca[KS], cb[KS];
+      half8 ca[WINDOW ? 2 * CW : KS], cb[WINDOW ? 1 : KS];
       {
         const char* c1 = sbase + SL.c_off(n_act - 1);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) ca[s] = *(const half8*)(c1 + s * 1024);
-        if (n_act >= 2) {
+        for (int s = 0; s < (WINDOW ? 2 * CW : KS); ++s) ca[s] = *(const half8*)(c1 + s * 1024);
+        if (!WINDOW && n_act >= 2) {
           const char* c2 = sbase + SL.c_off(n_act - 2);
 #pragma unroll
           for (int s = 0; s < KS; ++s) cb[s] = *(const half8*)(c2 + s * 1024);
         }
       }
+      // window mode: after its use by tile U of the layer that consumes cos_lc, slot U % CW takes tile U + CW -- of the
+      // same layer while U + CW < NT, else tile U + CW - NT of cos_{lc-1} (clamped to layer 0 at the end: never consumed)
+      auto window_refill = [&](int U, int lc) {
+        const int Un = U + CW < NT ? U + CW : U + CW - NT;
+        const int ln = U + CW < NT ? lc : (lc - 1 >= 0 ? lc - 1 : 0);
+        const char* cn = sbase + SL.c_off(ln);
+        ca[2 * (U % CW)] = *(const half8*)(cn + (2 * Un) * 1024);
+        ca[2 * (U % CW) + 1] = *(const half8*)(cn + (2 * Un + 1) * 1024);
+      };
       // dZ of the output layer as a B fragment: K slot 0 / 1 = d loss / d raw[..., 0 / 1]
       half8 dz_out = {0, 0, 0, 0, 0, 0, 0, 0};
       if (valid && h == 0) {
@@ -196,7 +212,12 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_kernel(DgradArgs a) {
           f32x16 acc = {0};
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aT, dz_out, acc, 0, 0, 0);
           half8 d0, d1;
-          dz_tile(acc, ca[2 * U], ca[2 * U + 1], d0, d1);
+          if constexpr (WINDOW) {
+            dz_tile(acc, ca[2 * (U % CW)], ca[2 * (U % CW) + 1], d0, d1);
+            window_refill(U, n_act - 1);
+          } else {
+            dz_tile(acc, ca[2 * U], ca[2 * U + 1], d0, d1);
+          }
           __builtin_nontemporal_store(d0, (half8*)(dzl + (2 * U) * 1024));
           __builtin_nontemporal_store(d1, (half8*)(dzl + (2 * U + 1) * 1024));
           pin_agpr(d0); pin_agpr(d1);
@@ -221,59 +242,78 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_kernel(DgradArgs a) {
         const char* cnext = sbase + SL.c_off(more_cos ? l - 3 : 0);
 #pragma unroll
         for (int U = 0; U < NT; ++U) {
-          const char* buf = smem + (blk & 1) * BLK;
-          {
-            // unconditional (the last PD tiles of a chunk re-read the final block): a branch around these loads makes
-            // hipcc's s_waitcnt insertion fall back to a conservative count that drains the prefetches every tile
-            const int nb = min(blk + PD, n_blocks - 1);
-#pragma unroll
-            for (int v = 0; v < VEC; ++v)   // block blk has left stage[U % PD] (written to LDS one tile ago)
-              stage[U % PD][v] = *(const f32x4*)(wT_hidden + (size_t)nb * BLK + (size_t)(v * DG_THREADS + tid) * 16);
-          }
           f32x16 acc = {0};
-          {
-            // A fragments PF k-steps ahead of their MFMAs; sched_barrier pins the reads there (hipcc would otherwise sink
-            // each read next to its use and expose the LDS latency on every k-step)
-            constexpr int PF = KS < 4 ? KS : 4;
-            const char* fb = buf + lane * 16;
-            half8 fhi[PF], flo[PF];
 #pragma unroll
-            for (int s = 0; s < PF; ++s) { fhi[s] = *(const half8*)(fb + s * 2048); flo[s] = *(const half8*)(fb + s * 2048 + 1024); }
-            __builtin_amdgcn_sched_barrier(0);
+          for (int hb = 0; hb < NB; ++hb) {
+            const char* buf = smem + (blk & 1) * BLK;
+            {
+              // unconditional (the last PD blocks of a chunk re-read the final block): a branch around these loads makes
+              // hipcc's s_waitcnt insertion fall back to a conservative count that drains the prefetches every tile
+              const int nb = min(blk + PD, n_blocks - 1);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(flo[s % PF], x[s], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fhi[s % PF], x[s], acc, 0, 0, 0);
-              if (s + PF < KS) {
-                fhi[s % PF] = *(const half8*)(fb + (s + PF) * 2048);
-                flo[s % PF] = *(const half8*)(fb + (s + PF) * 2048 + 1024);
-              }
-              __builtin_amdgcn_sched_barrier(0);
+              for (int v = 0; v < VEC; ++v)   // block blk has left this stage slot (written to LDS one block ago)
+                stage[(U * NB + hb) % PD][v] =
+                    *(const f32x4*)(wT_hidden + (size_t)nb * BLK + (size_t)(v * DG_THREADS + tid) * 16);
             }
-          }
-          half8 d0, d1;
-          dz_tile(acc, cc[2 * U], cc[2 * U + 1], d0, d1);
-          // this tile's cos registers are free again: refill (unconditionally, see above; the last layers of a chunk
-          // re-read layer 0's fragments, which nobody consumes)
-          cc[2 * U] = *(const half8*)(cnext + (2 * U) * 1024);
-          cc[2 * U + 1] = *(const half8*)(cnext + (2 * U + 1) * 1024);
-          __builtin_nontemporal_store(d0, (half8*)(dzl + (2 * U) * 1024));
-          __builtin_nontemporal_store(d1, (half8*)(dzl + (2 * U + 1) * 1024));
-          pin_agpr(d0); pin_agpr(d1);
-          y[2 * U] = d0; y[2 * U + 1] = d1;
+            {
+              // A fragments PF k-steps ahead of their MFMAs; sched_barrier pins the reads there (hipcc would otherwise
+              // sink each read next to its use and expose the LDS latency on every k-step)
+              constexpr int PF = HB < 4 ? HB : 4;
+              const char* fb = buf + lane * 16;
+              half8 fhi[PF], flo[PF];
 #pragma unroll
-          for (int v = 0; v < VEC; ++v)
-            *(f32x4*)(smem + ((blk + 1) & 1) * BLK + (size_t)(v * DG_THREADS + tid) * 16) = stage[(U + 1) % PD][v];
-          // LDS hand-off only: __syncthreads() would also drain every outstanding global load / store (vmcnt(0)) and
-          // with it the cos / weight prefetches that are meant to stay in flight across tiles
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-          ++blk;
+              for (int s = 0; s < PF; ++s) { fhi[s] = *(const half8*)(fb + s * 2048); flo[s] = *(const half8*)(fb + s * 2048 + 1024); }
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int s = 0; s < HB; ++s) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(flo[s % PF], x[hb * HB + s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fhi[s % PF], x[hb * HB + s], acc, 0, 0, 0);
+                if (s + PF < HB) {
+                  fhi[s % PF] = *(const half8*)(fb + (s + PF) * 2048);
+                  flo[s % PF] = *(const half8*)(fb + (s + PF) * 2048 + 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+            if (hb == NB - 1) {
+              half8 d0, d1;
+              if constexpr (WINDOW) {
+                dz_tile(acc, cc[2 * (U % CW)], cc[2 * (U % CW) + 1], d0, d1);
+                window_refill(U, l - 1);
+              } else {
+                dz_tile(acc, cc[2 * U], cc[2 * U + 1], d0, d1);
+                // this tile's cos registers are free again: refill (unconditionally, see above; the last layers of a
+                // chunk re-read layer 0's fragments, which nobody consumes)
+                cc[2 * U] = *(const half8*)(cnext + (2 * U) * 1024);
+                cc[2 * U + 1] = *(const half8*)(cnext + (2 * U + 1) * 1024);
+              }
+              __builtin_nontemporal_store(d0, (half8*)(dzl + (2 * U) * 1024));
+              __builtin_nontemporal_store(d1, (half8*)(dzl + (2 * U + 1) * 1024));
+              pin_agpr(d0); pin_agpr(d1);
+              y[2 * U] = d0; y[2 * U + 1] = d1;
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+              *(f32x4*)(smem + ((blk + 1) & 1) * BLK + (size_t)(v * DG_THREADS + tid) * 16) = stage[(U * NB + hb + 1) % PD][v];
+            // LDS hand-off only: __syncthreads() would also drain every outstanding global load / store (vmcnt(0)) and
+            // with it the cos / weight prefetches that are meant to stay in flight across tiles
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            ++blk;
+          }
         }
       };
       // layer l uses cos_{l-1}: ca holds cos_{n_act-1} (used by the out layer) -> the first hidden layer l = n_act - 1
       // uses cos_{n_act-2} = cb, the second ca (refilled with cos_{n_act-3} by the out layer below), and so on.
       int l = a.n_linear - 2;
+      if constexpr (WINDOW) {
+        for (; l - 1 >= 1; l -= 2) {
+          hidden_layer(l, xa, xb, ca);
+          hidden_layer(l - 1, xb, xa, ca);
+        }
+        if (l >= 1) hidden_layer(l, xa, xb, ca);
+        continue;
+      }
       if (l >= 1) {
         // refill ca (free since the out layer) with the cos of the second hidden layer
         if (l - 2 >= 0) {
@@ -390,7 +430,7 @@ extern "C" int sunerf_emission_integral_bwd(const float* raw, const float* z_val
 
 template <int D>
 static int launch_dgrad(const DgradArgs& a, hipStream_t stream) {
-  const size_t lds = 2 * (size_t)(D / 16) * 2048;
+  const size_t lds = 2 * (size_t)(D / 16 < 16 ? D / 16 : 16) * 2048;
   hipError_t e = hipFuncSetAttribute((const void*)dgrad_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   const int64_t n_groups = (a.n_rays + DG_WAVES - 1) / DG_WAVES;
@@ -417,6 +457,7 @@ extern "C" int sunerf_mlp_dgrad(const void* packedT, int d_filter, int n_linear,
     case 64: return launch_dgrad<64>(a, (hipStream_t)stream);
     case 128: return launch_dgrad<128>(a, (hipStream_t)stream);
     case 256: return launch_dgrad<256>(a, (hipStream_t)stream);
+    case 512: return launch_dgrad<512>(a, (hipStream_t)stream);
     default: return SUNERF_E_UNSUPPORTED;
   }
 }

@@ -26,7 +26,7 @@ struct WgradArgs {
   const char* dz_stash;
   const float* g_raw;
   const unsigned* g_absmax_bits;
-  float* partial;        // [n_linear][split][tile_r 8][tile_c 9 (8 = bias column)][reg 16][lane 64]
+  float* partial;        // [n_linear][split][tile_r T][tile_c T + 1 (T = bias column)][reg 16][lane 64], T = max(8, D/32)
   int64_t n_chunks_total;
   int64_t n_rays;
   int S, n_chunks;       // samples per ray, chunks per ray
@@ -64,9 +64,16 @@ __device__ __forceinline__ half8 join(half4 lo, half4 hi) {
 constexpr int NBUF = 4;   // LDS ring of chunk buffers (3 chunks of HBM latency cover)
 
 // KIND: 0 = in layer (X = encoding, 6 fragments), 1 = hidden layer, 2 = out layer (dZ built from g_raw)
+// tiles per side of the partial-sum workspace (bias column = index wg_tiles)
+__host__ __device__ constexpr int wg_tiles(int D) { return D / 32 > 8 ? D / 32 : 8; }
+// a workgroup covers at most 8 x 8 tiles (4 waves x 4 x 4 tiles = all 256 AGPRs): D = 512 is split over 2 x 2 workgroups
+__host__ __device__ constexpr int wg_quads(int D) { return D > 256 ? 2 : 1; }
+
 template <int D, int KIND>
-__device__ __forceinline__ void wgrad_body(const WgradArgs& a, char* smem, int layer, int split) {
-  constexpr int NT = D / 32, KS = D / 16;
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, char* smem, int layer, int split, int qa, int qb) {
+  constexpr int NQ = wg_quads(D), T = wg_tiles(D);
+  constexpr int NT = D / 32 / NQ, KS = D / 16 / NQ;         // tiles / fragments per side of THIS workgroup's block
+  constexpr int KSF = D / 16;                               // fragments per layer in the stashes
   constexpr int QR = NT >= 4 ? 4 : NT;                      // tiles per quadrant side
   constexpr int BFR = KS > SUNERF_KS0 ? KS : SUNERF_KS0;    // B-side fragments per buffer
   constexpr int BUF = (KS + BFR) * 1024;                    // one chunk buffer: A fragments | B fragments
@@ -74,13 +81,15 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, char* smem, int l
   constexpr int B_FRAGS = KIND == 0 ? SUNERF_KS0 : KS;
   constexpr int ROW_TILES = KIND == 2 ? 1 : NT;
   constexpr int COL_TILES = KIND == 0 ? SUNERF_KS0 / 2 : NT;
+  // the in layer has 3 column tiles and the out layer 1 row tile: their other workgroup blocks are empty
+  if ((KIND == 0 && qb > 0) || (KIND == 2 && qa > 0)) return;
   constexpr int PIECES = A_FRAGS + B_FRAGS;
   constexpr int PW = (PIECES + 3) / 4;                      // DMA instructions per wave and chunk (uniform)
   const StashLayout SL(D, a.n_linear);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n_act = a.n_linear - 1;
-  const size_t dz_chunk_bytes = (size_t)n_act * KS * 1024;
+  const size_t dz_chunk_bytes = (size_t)n_act * KSF * 1024;
   const float gscale = gscale_from_bits(*a.g_absmax_bits);
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   const unsigned dummy = lds0 + NBUF * BUF;
@@ -89,7 +98,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, char* smem, int l
   const int rq = wave >> 1, cq = wave & 1;
   const int r0 = rq * QR, c0 = cq * QR;
   const int nr = max(0, min(QR, ROW_TILES - r0)), nc = max(0, min(QR, COL_TILES - c0));
-  const bool do_bias = cq == 0 && nr > 0;
+  const bool do_bias = cq == 0 && qb == 0 && nr > 0;
 
   f32x16 acc[QR][QR];     // the 16 tiles fill the 256 AGPRs exactly
   float bsum[QR];         // db: per-lane partial sums of the A operand (row = lane & 31) over its 8-sample k slices
@@ -110,8 +119,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, char* smem, int l
 
   // DMA of one chunk: PIECES pieces of 1 KiB dealt round-robin to the 4 waves; every wave issues the same number PW of
   // instructions (surplus ones re-read piece 0 into a dummy slot) so that vmcnt accounting is uniform
-  const char* srcA0 = a.dz_stash + (size_t)layer * KS * 1024 + lane * 16;
-  const char* srcB0 = a.act_stash + (KIND == 0 ? 0 : SL.h_off(layer - 1)) + lane * 16;
+  const char* srcA0 = a.dz_stash + ((size_t)layer * KSF + (size_t)qa * KS) * 1024 + lane * 16;
+  const char* srcB0 = a.act_stash + (KIND == 0 ? 0 : SL.h_off(layer - 1) + (size_t)qb * KS * 1024) + lane * 16;
   const size_t act_chunk_bytes = SL.chunk_bytes();
   auto issue_chunk = [&](int64_t chunk, int buf) {
     const char* srcA = srcA0 + chunk * dz_chunk_bytes;
@@ -197,15 +206,16 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, char* smem, int l
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // surplus prefetches target our LDS: drain before exit
-  // ---- partial sums -> workspace [layer][split][tr 8][tc 9][reg][lane]; tc = 8 is the bias column ----
-  float* out = a.partial + ((size_t)layer * a.split + split) * 72 * 1024;
+  // ---- partial sums -> workspace [layer][split][tr T][tc T + 1][reg][lane]; tc = T is the bias column ----
+  float* out = a.partial + ((size_t)layer * a.split + split) * (T * (T + 1)) * 1024;
+  const int gr0 = qa * NT + r0, gc0 = qb * NT + c0;      // global tile coordinates of this wave's block
 #pragma unroll
   for (int i = 0; i < QR; ++i) {
     if (i < nr) {
 #pragma unroll
       for (int j = 0; j < QR; ++j)
         if (j < nc) {
-          float* t = out + ((size_t)(r0 + i) * 9 + (c0 + j)) * 1024;
+          float* t = out + ((size_t)(gr0 + i) * (T + 1) + (gc0 + j)) * 1024;
 #pragma unroll
           for (int r = 0; r < 16; ++r) t[r * 64 + lane] = acc[i][j][r];
         }
@@ -215,7 +225,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, char* smem, int l
 #pragma unroll
     for (int i = 0; i < QR; ++i) {
       const float v = bsum[i] + __shfl_xor(bsum[i], 32);
-      if (i < nr && lane < 32) out[((size_t)(r0 + i) * 9 + 8) * 1024 + lane] = v;
+      if (i < nr && lane < 32) out[((size_t)(gr0 + i) * (T + 1) + T) * 1024 + lane] = v;
     }
   }
 }
@@ -223,10 +233,13 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, char* smem, int l
 template <int D>
 __global__ __launch_bounds__(WG_THREADS, 1) void wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // NBUF chunk buffers + 1 KiB dummy target + slack
-  const int layer = blockIdx.x / a.split, split = blockIdx.x % a.split;
-  if (layer == 0) wgrad_body<D, 0>(a, smem, layer, split);
-  else if (layer == a.n_linear - 1) wgrad_body<D, 2>(a, smem, layer, split);
-  else wgrad_body<D, 1>(a, smem, layer, split);
+  constexpr int NQ = wg_quads(D);
+  const int q = blockIdx.x % (NQ * NQ), ls = blockIdx.x / (NQ * NQ);
+  const int layer = ls / a.split, split = ls % a.split;
+  const int qa = q / NQ, qb = q % NQ;
+  if (layer == 0) wgrad_body<D, 0>(a, smem, layer, split, qa, qb);
+  else if (layer == a.n_linear - 1) wgrad_body<D, 2>(a, smem, layer, split, qa, qb);
+  else wgrad_body<D, 1>(a, smem, layer, split, qa, qb);
 }
 
 // feature of fragment-order index f (= 16 s + 8 h + e) on the activation side / the encoding side
@@ -249,16 +262,17 @@ __global__ void reduce_grads_kernel(ReduceArgs a) {
   const int rows = (layer == a.n_linear - 1) ? a.d_out : D;
   const int cols = (layer == 0) ? SUNERF_ENC_DIM : D;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  // enumerate in tile order so that reads of the partials are coalesced: idx = ((tr*9 + tc)*16 + reg)*64 + lane
+  // enumerate in tile order so that reads of the partials are coalesced: idx = ((tr*(T+1) + tc)*16 + reg)*64 + lane
+  const int T = wg_tiles(D);
   const int row_tiles = (layer == a.n_linear - 1) ? 1 : D / 32;
   const int col_tiles = (layer == 0) ? SUNERF_KS0 / 2 : D / 32;
-  if (idx >= row_tiles * 9 * 1024) return;
+  if (idx >= row_tiles * (T + 1) * 1024) return;
   const int lane = idx & 63, reg = (idx >> 6) & 15, t = idx >> 10;
-  const int tr = t / 9, tc = t % 9;
-  if (tc != 8 && tc >= col_tiles) return;
+  const int tr = t / (T + 1), tc = t % (T + 1);
+  if (tc != T && tc >= col_tiles) return;
   int k = 0;
   int fa_row = acc_row(reg, lane >> 5);
-  if (tc == 8) {                                        // bias slot: 32 plain sums per row tile (reg 0, lanes 0..31)
+  if (tc == T) {                                        // bias slot: 32 plain sums per row tile (reg 0, lanes 0..31)
     if (reg != 0 || lane >= 32) return;
     fa_row = lane;
   } else {
@@ -269,21 +283,23 @@ __global__ void reduce_grads_kernel(ReduceArgs a) {
   const int fa = 32 * tr + fa_row;                      // fragment-order index on the dZ side
   const int j = (layer == a.n_linear - 1) ? fa : frag_feature_hidden(fa);   // out layer: feature index = output index
   if (j >= rows) return;
-  const float* p = a.partial + (size_t)layer * a.split * 72 * 1024 + ((size_t)tr * 9 + tc) * 1024 + reg * 64 + lane;
+  const size_t slot = (size_t)T * (T + 1) * 1024;
+  const float* p = a.partial + (size_t)layer * a.split * slot + ((size_t)tr * (T + 1) + tc) * 1024 + reg * 64 + lane;
   float sum = 0.f;
-  for (int s = 0; s < a.split; ++s) sum += p[(size_t)s * 72 * 1024];
+  for (int s = 0; s < a.split; ++s) sum += p[(size_t)s * slot];
   const float m = __uint_as_float(*a.g_absmax_bits);
   float inv = 1.f;
   if (m > 0.f) { int e; frexpf(m, &e); inv = ldexpf(1.f, e - 10); }
-  float* dst = (tc == 8) ? a.gb[layer] + j : a.gW[layer] + (size_t)j * cols + k;
+  float* dst = (tc == T) ? a.gb[layer] + j : a.gW[layer] + (size_t)j * cols + k;
   *dst = a.accumulate ? *dst + sum * inv : sum * inv;
 }
 
 }  // namespace
 
-extern "C" size_t sunerf_wgrad_workspace_bytes(int n_linear, int split) {
-  if (n_linear < 2 || split < 1) return 0;
-  return (size_t)n_linear * split * 72 * 1024 * sizeof(float);
+extern "C" size_t sunerf_wgrad_workspace_bytes(int d_filter, int n_linear, int split) {
+  if (n_linear < 2 || split < 1 || d_filter < 32 || d_filter % 32) return 0;
+  const size_t T = wg_tiles(d_filter);
+  return (size_t)n_linear * split * T * (T + 1) * 1024 * sizeof(float);
 }
 
 extern "C" int sunerf_mlp_wgrad(int d_filter, int n_linear, int d_out, const void* act_stash, const void* dz_stash,
@@ -294,7 +310,7 @@ extern "C" int sunerf_mlp_wgrad(int d_filter, int n_linear, int d_out, const voi
   if (n_rays < 0 || n_samples < 2 || split < 1) return SUNERF_E_BADARG;
   if (n_rays > 0 && (!act_stash || !dz_stash || !g_raw || !g_absmax || !workspace)) return SUNERF_E_BADARG;
   if (n_linear < 2 || n_linear > SUNERF_MAX_LAYERS || d_out < 1 || d_out > 2) return SUNERF_E_UNSUPPORTED;
-  if (d_filter != 64 && d_filter != 128 && d_filter != 256) return SUNERF_E_UNSUPPORTED;
+  if (d_filter != 64 && d_filter != 128 && d_filter != 256 && d_filter != 512) return SUNERF_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int n_chunks = (n_samples + 31) / 32;
   ReduceArgs r;
@@ -318,26 +334,29 @@ extern "C" int sunerf_mlp_wgrad(int d_filter, int n_linear, int d_out, const voi
   a.g_absmax_bits = (const unsigned*)g_absmax; a.partial = (float*)workspace;
   a.n_chunks_total = n_rays * n_chunks; a.n_rays = n_rays; a.S = n_samples; a.n_chunks = n_chunks;
   a.n_linear = n_linear; a.split = split;
-  const int ks = d_filter / 16;
+  const int nq = wg_quads(d_filter);
+  const int ks = d_filter / 16 / nq;       // fragments per side of one workgroup's block
   // ring + 1 KiB dummy DMA target + slack for the unguarded operand reads of out-of-shape tiles
   const size_t lds = (size_t)NBUF * ((size_t)ks + (ks > SUNERF_KS0 ? ks : SUNERF_KS0)) * 1024 + 1024 + 16 * 1024;
   a.lds_bytes = (int)lds;
   const void* fn = d_filter == 64 ? (const void*)wgrad_kernel<64> : d_filter == 128 ? (const void*)wgrad_kernel<128>
-                                                                                     : (const void*)wgrad_kernel<256>;
+                 : d_filter == 256 ? (const void*)wgrad_kernel<256> : (const void*)wgrad_kernel<512>;
   if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return (int)e;
   // every (layer, split) slot of the workspace that the reduce kernel reads is written by exactly one workgroup; slots of
   // workgroups without chunks hold zeros from their zero-initialised accumulators
   SUNERF_CLEAR_ERROR();
-  const unsigned grid = (unsigned)(n_linear * split);
+  const unsigned grid = (unsigned)(n_linear * split * nq * nq);
   switch (d_filter) {
     case 64: hipLaunchKernelGGL(wgrad_kernel<64>, dim3(grid), dim3(WG_THREADS), lds, st, a); break;
     case 128: hipLaunchKernelGGL(wgrad_kernel<128>, dim3(grid), dim3(WG_THREADS), lds, st, a); break;
-    default: hipLaunchKernelGGL(wgrad_kernel<256>, dim3(grid), dim3(WG_THREADS), lds, st, a); break;
+    case 256: hipLaunchKernelGGL(wgrad_kernel<256>, dim3(grid), dim3(WG_THREADS), lds, st, a); break;
+    default: hipLaunchKernelGGL(wgrad_kernel<512>, dim3(grid), dim3(WG_THREADS), lds, st, a); break;
   }
   SUNERF_CHECK_LAUNCH();
   r.partial = (const float*)workspace; r.g_absmax_bits = (const unsigned*)g_absmax; r.n_linear = n_linear; r.D = d_filter;
   r.d_out = d_out; r.split = split; r.accumulate = accumulate;
-  hipLaunchKernelGGL(reduce_grads_kernel, dim3(72 * 1024 / 256, n_linear), dim3(256), 0, st, r);
+  const unsigned tt = (unsigned)wg_tiles(d_filter);
+  hipLaunchKernelGGL(reduce_grads_kernel, dim3(tt * (tt + 1) * 1024 / 256, n_linear), dim3(256), 0, st, r);
   SUNERF_CHECK_LAUNCH();
   return 0;
 }

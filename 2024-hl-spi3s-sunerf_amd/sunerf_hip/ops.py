@@ -13,7 +13,7 @@ from . import lib as _l
 SAMPLER_STRATIFIED = 0
 SAMPLER_SPHERICAL = 1
 SUPPORTED_D_FILTER = (64, 128, 256, 512)
-TRAINABLE_D_FILTER = (64, 128, 256)     # the backward kernels do not cover the 512-wide net yet
+TRAINABLE_D_FILTER = (64, 128, 256, 512)
 _workspaces = {}                        # device -> scratch for the d_filter = 512 render kernel (per stream use is serial)
 
 
@@ -177,10 +177,12 @@ def hier_resample(z_vals, weights, u: torch.Tensor) -> Tuple[torch.Tensor, torch
     return new_z, z_comb
 
 
-def wgrad_split(n_linear: int, n_cus: int = 256) -> int:
-    """Partial sums per layer in sunerf_mlp_wgrad: n_linear * split workgroups must fit the chip in ONE wave (one
-    workgroup per CU, all about equally long): 9 layers -> 28 (252 workgroups); 288 would take two rounds."""
-    return max(1, n_cus // n_linear)
+def wgrad_split(n_linear: int, n_cus: int = 256, d_filter: int = 256) -> int:
+    """Partial sums per layer in sunerf_mlp_wgrad: n_linear * split (* 4 workgroup blocks at d_filter = 512) workgroups
+    must fit the chip in ONE wave (one workgroup per CU, all about equally long): 9 layers -> 28 (252 workgroups);
+    288 would take two rounds."""
+    blocks = 4 if d_filter > 256 else 1
+    return max(1, n_cus // (n_linear * blocks))
 
 
 def emission_render_bwd(packed: PackedMLP, rays_o, rays_d, z_vals, raw, stash, g_image, g_reg, g_reg_const: float,
@@ -223,8 +225,8 @@ def mlp_backward(packed: PackedMLP, g_raw, absmax, stash, grad_weights: Sequence
     st = lib.sunerf_mlp_dgrad(_ptr(packed.transposed()), D, nl, _ptr(g_raw), _ptr(absmax), _ptr(stash), _ptr(dz), n, s,
                               stream)
     _l.check(st, 'sunerf_mlp_dgrad')
-    split = wgrad_split(nl, torch.cuda.get_device_properties(dev).multi_processor_count)
-    ws = torch.empty(lib.sunerf_wgrad_workspace_bytes(nl, split), dtype=torch.uint8, device=dev)
+    split = wgrad_split(nl, torch.cuda.get_device_properties(dev).multi_processor_count, D)
+    ws = torch.empty(lib.sunerf_wgrad_workspace_bytes(packed.d_filter, nl, split), dtype=torch.uint8, device=dev)
     for i, (gw, gb) in enumerate(zip(grad_weights, grad_biases)):
         d_in = 84 if i == 0 else D
         d_o = packed.d_out if i == nl - 1 else D

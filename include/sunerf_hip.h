@@ -117,14 +117,14 @@ int sunerf_emission_render_fwd(const void* packed, int d_filter, int n_linear,
  *   g_reg    : (N,S) gradient w.r.t. the 'regularization' output, or NULL with g_reg_const (the usual
  *              lambda / (N*S) of regularization.mean(), sunerf.py:118-119)
  *   g_absmax : 4-byte device scratch (bit pattern of max |g_raw|; selects the fp16 gradient scale on the device)
- *   workspace: sunerf_wgrad_workspace_bytes(n_linear, split) bytes; split = number of partial sums per layer
+ *   workspace: sunerf_wgrad_workspace_bytes(d_filter, n_linear, split) bytes; split = number of partial sums per layer
  *   accumulate != 0 adds to grad_* instead of overwriting (autograd .grad accumulation)
  * ---------------------------------------------------------------------------------------------------------- */
 size_t sunerf_packed_mlp_t_bytes(int d_filter, int n_linear);
 int sunerf_pack_mlp_t(const float* const* weights_host, int n_linear, int d_filter, int d_out, void* packedT,
                       void* stream);
 size_t sunerf_dz_stash_bytes(int64_t n_rays, int n_samples, int d_filter, int n_linear);
-size_t sunerf_wgrad_workspace_bytes(int n_linear, int split);
+size_t sunerf_wgrad_workspace_bytes(int d_filter, int n_linear, int split);
 
 int sunerf_emission_integral_bwd(const float* raw, const float* z_vals, const float* rays_o, const float* rays_d,
                                  const float* g_image, const float* g_reg, float g_reg_const, float reg_radius,

@@ -39,7 +39,8 @@ def test_size_helpers(lib):
     assert lib.sunerf_act_stash_bytes(10, 128, 256, 9) == (10 * 4 + 1) * (6 + 8 * 32) * 1024
     assert lib.sunerf_act_stash_bytes(10, 130, 256, 9) == (10 * 5 + 1) * (6 + 8 * 32) * 1024      # ragged last chunk
     assert lib.sunerf_dz_stash_bytes(10, 128, 256, 9) == (10 * 4 + 1) * 8 * 16 * 1024
-    assert lib.sunerf_wgrad_workspace_bytes(9, 32) == 9 * 32 * 72 * 1024 * 4   # 8 x (8 + bias column) tiles
+    assert lib.sunerf_wgrad_workspace_bytes(256, 9, 32) == 9 * 32 * 72 * 1024 * 4   # 8 x (8 + bias column) tiles
+    assert lib.sunerf_wgrad_workspace_bytes(512, 9, 7) == 9 * 7 * 16 * 17 * 1024 * 4
 
 
 def test_argument_errors_without_gpu(lib):
