@@ -14,6 +14,7 @@ from sunerf.rendering.base_tracing import SuNeRFRendering
 from sunerf.rendering.emission import EmissionRadiativeTransfer
 from sunerf.rendering.density_temperature import DensityTemperatureRadiativeTransfer
 from sunerf.train.scaling import ImageAsinhScaling
+from sunerf_hip.train import ClipAdam, training_loss
 
 try:  # pragma: no cover - depends on the environment
     from pytorch_lightning import LightningModule
@@ -43,10 +44,30 @@ class BaseSuNeRFModule(LightningModule):
         self.lr_config = {'start': 1e-4, 'end': 1e-5, 'iterations': 1e6} if lr_config is None else lr_config
 
     def configure_optimizers(self):
-        self.optimizer = torch.optim.Adam(self.rendering.parameters(), lr=self.lr_config['start'])
+        # sunerf.py:31: Adam(lr = start).  ClipAdam is the same update on one flat buffer (and can take the gradient
+        # clip that run_emission.py:72 configures on the Trainer: fit_steps below sets optimizer.max_norm).
+        self.optimizer = ClipAdam(self.rendering.parameters(), lr=self.lr_config['start'])
         self.scheduler = ExponentialLR(self.optimizer, gamma=(self.lr_config['end'] / self.lr_config['start']) ** (
                 1 / self.lr_config['iterations']))
         return [self.optimizer], [self.scheduler]
+
+    # sunerf.py:105-107 asserts on NaN / Inf in every step, which costs a device -> host round trip.  True (default)
+    # keeps that behaviour with ONE 4-byte read per step; False defers the check to ``check_finite()`` (the optimiser
+    # step is skipped on the device for a step that saw non-finite outputs, so the weights stay intact meanwhile).
+    strict_finite_check = True
+
+    def _finish_step(self, loss, stats):
+        self.last_stats = stats
+        if self.strict_finite_check:
+            self.check_finite()
+        self.log('loss', loss)
+        self.log('train', {'coarse': stats[1], 'fine': stats[2], 'regularization': stats[3], 'psnr': stats[4]})
+        return loss
+
+    def check_finite(self):
+        stats = getattr(self, 'last_stats', None)
+        if stats is not None:
+            assert stats[5].item() == 0, '! [Numerical Alert] an output contains NaN or Inf.'
 
     def on_train_batch_end(self, *args, **kwargs):
         if self.scheduler.get_last_lr()[0] > 5e-5:
@@ -72,6 +93,12 @@ class BaseSuNeRFModule(LightningModule):
         self.validation_outputs = {}
 
 
+def _other_outputs(outputs):
+    """Outputs that only take part in the finite check (the images and the regularization are read by the loss anyway)."""
+    skip = ('coarse_image', 'fine_image', 'regularization', 'image')     # 'image' is fine_image (base_tracing.py:107)
+    return [v for k, v in outputs.items() if k not in skip]
+
+
 def save_state(sunerf: BaseSuNeRFModule, data_module, save_path):
     """sunerf.py:62-74: pickles the rendering module + data configuration (the ``.snf`` file)."""
     output_path = '/'.join(save_path.split('/')[0:-1])
@@ -94,30 +121,26 @@ class EmissionSuNeRFModule(BaseSuNeRFModule):
         self.image_scaling = ImageAsinhScaling(**image_scaling_config)
         self.mse_loss = nn.MSELoss()
 
-    def _loss(self, outputs, target_image):
-        target_image = self.image_scaling(target_image)
-        coarse_loss = self.mse_loss(self.image_scaling(outputs['coarse_image']), target_image)
-        fine_loss = self.mse_loss(self.image_scaling(outputs['fine_image']), target_image)
-        regularization_loss = outputs['regularization'].mean()
-        loss = (self.lambda_image * (coarse_loss + fine_loss) + self.lambda_regularization * regularization_loss)
-        return loss, coarse_loss, fine_loss, regularization_loss
+    def _asinh_constants(self):
+        """(vmax, a) of the image scaling as host floats, read from the module's buffers once (not per step: a device ->
+        host copy each)."""
+        key = (self.image_scaling.vmax.data_ptr(), self.image_scaling.vmax._version, self.image_scaling.a._version)
+        if getattr(self, '_asinh_key', None) != key:
+            self._asinh_key = key
+            self._asinh = (float(self.image_scaling.vmax), float(self.image_scaling.a))
+        return self._asinh
 
     def training_step(self, batch, batch_nb):
         tracing = batch['tracing']
         rays, time, target_image = tracing['rays'], tracing['time'], tracing['target_image']
         rays_o, rays_d = rays[:, 0].contiguous(), rays[:, 1].contiguous()
         outputs = self.rendering(rays_o, rays_d, time)
-
-        # one fused finite check instead of the reference's 16 host syncs (sunerf.py:105-107); same failure mode
-        finite = torch.stack([torch.isfinite(v).all() for v in outputs.values()]).all()
-        assert bool(finite), '! [Numerical Alert] an output contains NaN or Inf.'
-
-        loss, coarse_loss, fine_loss, regularization_loss = self._loss(outputs, target_image)
-        with torch.no_grad():
-            psnr = -10. * torch.log10(fine_loss)
-        self.log('loss', loss)
-        self.log('train', {'coarse': coarse_loss, 'fine': fine_loss, 'regularization': regularization_loss, 'psnr': psnr})
-        return loss
+        # sunerf.py:105-125 in one kernel: finite check of all outputs, asinh scaling, 2 x MSE, regularization mean, psnr
+        loss, stats = training_loss(outputs['coarse_image'], outputs['fine_image'], target_image.reshape(-1, 1),
+                                    outputs['regularization'], self.lambda_image, self.lambda_regularization,
+                                    asinh_scaling=self._asinh_constants(),
+                                    finite_check=_other_outputs(outputs))
+        return self._finish_step(loss, stats)
 
     def validation_step(self, batch, batch_nb, **kwargs):
         dataloader_idx = kwargs['dataloader_idx'] if 'dataloader_idx' in kwargs else 0
@@ -155,6 +178,15 @@ class DensityTemperatureSuNeRFModule(BaseSuNeRFModule):
                                                  tracing['wavelength'])
         rays_o, rays_d = rays[:, 0].contiguous(), rays[:, 1].contiguous()
         outputs = self.rendering.forward(rays_o, rays_d, time, wavelengths)
+        if not isinstance(self.loss, nn.MSELoss) or self.loss.reduction != 'mean':
+            return self._training_step_generic_loss(outputs, target_image)
+        loss, stats = training_loss(outputs['coarse_image'], outputs['fine_image'], target_image,
+                                    outputs['regularization'], self.lambda_image, self.lambda_regularization,
+                                    asinh_scaling=None, finite_check=_other_outputs(outputs))
+        return self._finish_step(loss, stats)
+
+    def _training_step_generic_loss(self, outputs, target_image):
+        """A user-supplied loss module other than nn.MSELoss (sunerf.py:159 takes any callable): torch ops."""
         finite = torch.stack([torch.isfinite(v).all() for v in outputs.values()]).all()
         assert bool(finite), '! [Numerical Alert] an output contains NaN or Inf.'
         coarse_loss = self.loss(outputs['coarse_image'], target_image)
@@ -185,13 +217,14 @@ def fit_steps(module: BaseSuNeRFModule, batches, gradient_clip_val=0.5):
     """Minimal trainer loop with the semantics run_emission.py configures on the Lightning Trainer
     (run_emission.py:65-75): backward, clip_grad_norm_(0.5), Adam step, on_train_batch_end."""
     (optimizer,), _ = module.configure_optimizers()
+    optimizer.max_norm = gradient_clip_val          # clip fused into the optimiser step (norm and coefficient stay on device)
     losses = []
     for i, batch in enumerate(batches):
-        optimizer.zero_grad(set_to_none=True)
+        optimizer.zero_grad()
         loss = module.training_step(batch, i)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(module.rendering.parameters(), gradient_clip_val)
-        optimizer.step()
+        stats = getattr(module, 'last_stats', None)
+        optimizer.step(skip_if_positive=None if stats is None else stats[5:6])
         module.on_train_batch_end()
         losses.append(loss.detach())
     return losses

@@ -1,0 +1,194 @@
+"""Output side of the render path: fused training loss and clip + Adam step, no host synchronisation.
+
+``training_loss``   the loss section of the reference's ``training_step`` (sunerf/model/sunerf.py:105-125, :185-200) as ONE
+                    kernel behind an autograd node: finite check, asinh scaling, 2 x MSE, regularization mean, PSNR.
+``ClipAdam``        ``clip_grad_norm_(params, max_norm)`` + ``torch.optim.Adam.step()`` (+ the 1 / world averaging of the
+                    all-reduced gradients) as two kernels over ONE flat parameter / gradient / moment buffer.
+"""
+import ctypes
+from typing import Dict, Iterable, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import lib as _l
+from .ops import _dev, _ptr, _stream
+
+STAT_KEYS = ('loss', 'coarse', 'fine', 'regularization', 'psnr', 'non_finite')
+_ws = {}      # (device, stream) -> zero-initialised reduction workspace
+
+
+def _workspace(dev) -> torch.Tensor:
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _ws.get(key)
+    if ws is None:
+        ws = _ws[key] = torch.zeros(_l.load().sunerf_train_workspace_bytes(), dtype=torch.uint8, device=dev)
+    return ws
+
+
+class _TrainingLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, coarse, fine, target, reg, cfg):
+        lib = _l.load()
+        dev = coarse.device
+        coarse_c, fine_c = _dev(coarse, 'coarse_image'), _dev(fine, 'fine_image')
+        target_c = _dev(target, 'target_image', coarse.shape)
+        if fine.shape != coarse.shape:
+            raise ValueError('coarse_image and fine_image differ in shape')
+        n = coarse_c.numel()
+        reg_c = _dev(reg, 'regularization') if reg is not None else None
+        n_reg = reg_c.numel() if reg_c is not None else 0
+        extras = [_dev(t.detach(), 'finite-check tensor') for t in cfg['finite_check']]
+        ptrs = (ctypes.c_void_p * max(1, len(extras)))(*[t.data_ptr() for t in extras])
+        sizes = (ctypes.c_int64 * max(1, len(extras)))(*[t.numel() for t in extras])
+        g_coarse, g_fine = torch.empty_like(coarse_c), torch.empty_like(fine_c)
+        stats = torch.empty(8, dtype=torch.float32, device=dev)
+        ws = _workspace(dev)
+        scaling = cfg['scaling']
+        st = lib.sunerf_training_loss(_ptr(coarse_c), _ptr(fine_c), _ptr(target_c), n, _ptr(reg_c), n_reg, ptrs, sizes,
+                                      len(extras), 1 if scaling else 0, scaling[0] if scaling else 1.0,
+                                      scaling[1] if scaling else 1.0, cfg['lambda_image'], cfg['lambda_regularization'],
+                                      _ptr(g_coarse), _ptr(g_fine), _ptr(stats), _ptr(ws), ws.numel(), _stream(dev))
+        _l.check(st, 'sunerf_training_loss')
+        ctx.save_for_backward(g_coarse, g_fine)
+        ctx.reg_shape = None if reg is None else tuple(reg.shape)
+        ctx.reg_grad = cfg['lambda_regularization'] / n_reg if n_reg else 0.0
+        ctx.mark_non_differentiable(stats)
+        return stats[0], stats
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_stats):
+        g_coarse, g_fine = ctx.saved_tensors
+        g_reg = None
+        if ctx.reg_shape is not None and ctx.needs_input_grad[3]:
+            g_reg = (g_loss * ctx.reg_grad).expand(ctx.reg_shape)
+        return g_coarse * g_loss, g_fine * g_loss, None, g_reg, None
+
+
+def training_loss(coarse_image: torch.Tensor, fine_image: torch.Tensor, target_image: torch.Tensor,
+                  regularization: Optional[torch.Tensor], lambda_image: float = 1.0, lambda_regularization: float = 1.0,
+                  asinh_scaling: Optional[Sequence[float]] = None, finite_check: Iterable[torch.Tensor] = ()):
+    """``lambda_image * (MSE(s(coarse), s(target)) + MSE(s(fine), s(target))) + lambda_regularization * mean(reg)``
+    with ``s`` = ``ImageAsinhScaling(vmax, a)`` when ``asinh_scaling = (vmax, a)`` is given, identity otherwise.
+
+    Returns ``(loss, stats)``: ``loss`` is a differentiable 0-dim tensor; ``stats`` an 8-float device tensor
+    (see ``STAT_KEYS``; ``stats[5]`` counts NaN / Inf values among the images, the regularization and ``finite_check``)."""
+    cfg = {'lambda_image': float(lambda_image), 'lambda_regularization': float(lambda_regularization),
+           'scaling': None if asinh_scaling is None else (float(asinh_scaling[0]), float(asinh_scaling[1])),
+           'finite_check': list(finite_check)}
+    if len(cfg['finite_check']) > 8:
+        raise ValueError('at most 8 extra tensors can take part in the finite check')
+    return _TrainingLoss.apply(coarse_image, fine_image, target_image, regularization, cfg)
+
+
+def stats_dict(stats: torch.Tensor) -> Dict[str, torch.Tensor]:
+    return {k: stats[i] for i, k in enumerate(STAT_KEYS)}
+
+
+class ClipAdam(torch.optim.Optimizer):
+    """Adam (torch.optim.Adam semantics: no weight decay, no amsgrad) with the gradient clip fused in, on flat buffers.
+
+    On construction all parameters are moved into one flat fp32 buffer (``p.data`` become views of it), ``p.grad`` into a
+    second one (so backward kernels write straight into the buffer that is all-reduced), and the two moment buffers are
+    flat as well.  ``step()`` = optional sum all-reduce over ``group`` -> ||g / world|| -> clip -> Adam, two kernels, and
+    no ``.item()``: the learning rate and bias corrections are host scalars, the norm stays on the device.
+
+    ``param_groups`` carries ``lr`` / ``betas`` / ``eps`` like torch's Adam, so ``ExponentialLR`` (sunerf.py:32) works
+    unchanged.  ``max_norm=None`` leaves clipping to the caller (e.g. Lightning's ``gradient_clip_val``)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm: Optional[float] = None, group=None):
+        params = [p for p in params]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        if len(self.param_groups) != 1:
+            raise ValueError('ClipAdam keeps one flat buffer: a single parameter group')
+        self.max_norm = max_norm
+        self.group = group
+        self._params = [p for p in self.param_groups[0]['params'] if p.requires_grad]
+        if not self._params:
+            raise ValueError('no trainable parameters')
+        dev = self._params[0].device
+        if dev.type != 'cuda' or any(p.device != dev or p.dtype != torch.float32 for p in self._params):
+            raise _l.SunerfHipError('ClipAdam needs float32 parameters on one ROCm device')
+        n = sum(p.numel() for p in self._params)
+        self.flat_params = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.norm = torch.zeros(2, dtype=torch.float32, device=dev)      # total gradient norm, clip coefficient
+        self.step_count = 0
+        self._grad_views = []
+        off = 0
+        for p in self._params:
+            k = p.numel()
+            view = self.flat_params[off:off + k].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            gv = self.flat_grads[off:off + k].view_as(p)
+            p.grad = gv
+            self._grad_views.append(gv)
+            self.state[p] = {'step': torch.tensor(0.), 'exp_avg': self.exp_avg[off:off + k].view_as(p),
+                             'exp_avg_sq': self.exp_avg_sq[off:off + k].view_as(p)}
+            off += k
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Zeroes the flat gradient buffer and re-attaches the views (``set_to_none`` is ignored: the backward kernels
+        and the all-reduce work in place on the bucket)."""
+        self.flat_grads.zero_()
+        for p, gv in zip(self._params, self._grad_views):
+            p.grad = gv
+
+    def _collect(self):
+        for p, gv in zip(self._params, self._grad_views):   # autograd may have put a fresh tensor into .grad
+            if p.grad is None:
+                gv.zero_()
+            elif p.grad.data_ptr() != gv.data_ptr():
+                gv.copy_(p.grad)
+            p.grad = gv
+
+    @torch.no_grad()
+    def step(self, closure=None, skip_if_positive: Optional[torch.Tensor] = None):
+        loss = closure() if closure is not None else None
+        lib = _l.load()
+        self._collect()
+        world = 1
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            world = dist.get_world_size(self.group)
+            dist.all_reduce(self.flat_grads, op=dist.ReduceOp.SUM, group=self.group)
+        g = self.param_groups[0]
+        self.step_count += 1
+        dev = self.flat_params.device
+        ws = _workspace(dev)
+        max_norm = float(self.max_norm) if self.max_norm else 0.0
+        st = lib.sunerf_clip_adam_step(_ptr(self.flat_params), _ptr(self.flat_grads), _ptr(self.exp_avg),
+                                       _ptr(self.exp_avg_sq), self.flat_params.numel(), float(g['lr']),
+                                       float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), max_norm, 1.0 / world,
+                                       self.step_count, _ptr(skip_if_positive), _ptr(self.norm), _ptr(ws), ws.numel(),
+                                       _stream(dev))
+        _l.check(st, 'sunerf_clip_adam_step')
+        for p in self._params:
+            self.state[p]['step'] += 1
+        # the kernels wrote through raw pointers: tell autograd / the packed-weights cache that the values changed
+        torch.autograd.graph.increment_version(self._params)
+        return loss
+
+    def load_state_dict(self, state_dict):
+        """Accepts a ``torch.optim.Adam`` state dict (reference checkpoints): moments are copied into the flat buffers."""
+        groups = state_dict['param_groups']
+        ids = groups[0]['params']
+        for k in ('lr', 'betas', 'eps'):
+            if k in groups[0]:
+                self.param_groups[0][k] = groups[0][k]
+        all_params = self.param_groups[0]['params']
+        steps = []
+        for pid, p in zip(ids, all_params):
+            st = state_dict['state'].get(pid)
+            if st is None or p not in self.state:
+                continue
+            self.state[p]['exp_avg'].copy_(st['exp_avg'])
+            self.state[p]['exp_avg_sq'].copy_(st['exp_avg_sq'])
+            self.state[p]['step'] = torch.as_tensor(float(st['step']))
+            steps.append(int(float(st['step'])))
+        if steps:
+            if len(set(steps)) != 1:
+                raise ValueError('parameters with different step counts cannot share the fused bias correction')
+            self.step_count = steps[0]

@@ -168,6 +168,41 @@ int sunerf_dt_integral_bwd(const float* raw, const float* z_vals, const float* r
                            void* g_absmax, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Output side of the path: training loss and optimiser step without host synchronisation.
+ *
+ * sunerf_training_loss replaces EmissionSuNeRFModule.training_step's loss section, sunerf/model/sunerf.py:105-125
+ * (finite asserts :105-107, ImageAsinhScaling sunerf/train/scaling.py:17-28, 2 x nn.MSELoss, regularization.mean(),
+ * psnr) and, with scaling = 0, DensityTemperatureSuNeRFModule.training_step sunerf.py:185-200 (plain MSE).
+ *   coarse_image / fine_image / target_image : n = N * W floats each;  regularization : n_reg floats (may be 0)
+ *   finite_check_host[n_finite_check <= 8]   : HOST arrays of further device tensors (+ sizes) that only take part in
+ *                                              the NaN / Inf count (z_vals, height_map, ...: sunerf.py:105-107)
+ *   scaling 1 = asinh(x / vmax / a) / asinh(1 / a) applied to all three images; 0 = none
+ *   g_coarse / g_fine : d loss / d coarse_image, d loss / d fine_image (n floats each); d loss / d regularization is
+ *                       the constant lambda_regularization / n_reg
+ *   stats (8 floats, device): loss, coarse MSE, fine MSE, regularization mean, psnr, number of non-finite values, 0, 0
+ *   workspace: sunerf_train_workspace_bytes() bytes, ZERO-INITIALISED once by the caller (the kernels leave it zeroed);
+ *              one workspace serves one stream
+ *
+ * sunerf_clip_adam_step replaces torch.nn.utils.clip_grad_norm_(params, max_norm) (Lightning gradient_clip_val,
+ * run_emission.py:72) followed by torch.optim.Adam.step() (sunerf.py:31) on ONE flat fp32 buffer:
+ *   g = grads * grad_scale (1 / world size after a sum all-reduce); total = ||g||_2; g *= min(1, max_norm / (total + 1e-6));
+ *   m += (1 - beta1)(g - m); v = beta2 v + (1 - beta2) g g; p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ *   max_norm <= 0 disables clipping (norm_out / workspace may then be NULL); step counts from 1;
+ *   skip_if_positive: optional device float (e.g. stats + 5); a value > 0 leaves params and moments untouched;
+ *   norm_out (2 floats, device): total norm, clip coefficient.  grads holds the scaled, clipped gradient afterwards.
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t sunerf_train_workspace_bytes(void);
+int sunerf_training_loss(const float* coarse_image, const float* fine_image, const float* target_image, int64_t n,
+                         const float* regularization, int64_t n_reg, const float* const* finite_check_host,
+                         const int64_t* finite_check_sizes_host, int n_finite_check, int scaling, float vmax, float a,
+                         float lambda_image, float lambda_regularization, float* g_coarse, float* g_fine, float* stats,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int sunerf_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                          double beta1, double beta2, double eps, float max_norm, float grad_scale, int64_t step,
+                          const float* skip_if_positive, float* norm_out, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Hierarchical (inverse-CDF) resampling + merge.
  * Replaces HierarchicalSampler.forward / sample_pdf, sampling.py:111-169 (perturb=False: u = linspace(0,1,S_f),
  * passed in as the tensor `u` [S_f] so that torch.linspace's own fp32 values are used; or a per-ray u [N,S_f]

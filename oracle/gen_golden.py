@@ -14,6 +14,10 @@ Fixtures:
   g5_emission_e2e   shimmed two-pass emission forward: all 8 outputs + training loss (sunerf.py:110-120)
                     + gradients of every parameter, d_filter=64
   g5b_emission_d256 same at d_filter=256 (weights stored), forward outputs + loss only
+  g6_dt_e2e         DensityTemperatureRadiativeTransfer two-pass forward + loss + gradients ("Interp1D restated")
+  g7_train_step     loss section of training_step (reference ImageAsinhScaling + nn.MSELoss, sunerf.py:110-122) with
+                    its image gradients, and 4 steps of clip_grad_norm_(0.5) + torch.optim.Adam(lr=1e-4) on three
+                    tensors (what Lightning 1.9.3's gradient_clip_val + configure_optimizers, sunerf.py:31, execute)
 """
 import os
 import sys
@@ -176,8 +180,58 @@ def main():
     arrays.update(state_arrays('sd__', dt))
     arrays.update({'grad__' + k.replace('.', '__'): p.grad for k, p in dt.named_parameters()})
     npz('g6_dt_e2e', **arrays)
+    gen_g7(ref)
     ref_import.release_reference()
 
 
+def gen_g7(ref):
+    """Loss section + optimiser of the reference training step (pytorch_lightning itself is not importable here: the
+    two torch calls it makes for ``gradient_clip_val=0.5`` and ``optimizer.step()`` are issued directly)."""
+    g = torch.Generator().manual_seed(11)
+    n, s = 257, 48
+    scaling = ref.train.scaling.ImageAsinhScaling(vmax=1, a=0.005)
+    coarse = (torch.rand(n, 1, generator=g) * 1.5).requires_grad_(True)
+    fine = (torch.rand(n, 1, generator=g) * 1.5).requires_grad_(True)
+    target = torch.rand(n, 1, generator=g)
+    reg = (torch.rand(n, s, generator=g) * 1e-2).requires_grad_(True)
+    mse = torch.nn.MSELoss()
+    lam_img, lam_reg = 1.0, 0.5
+    ts = scaling(target)
+    coarse_loss, fine_loss = mse(scaling(coarse), ts), mse(scaling(fine), ts)
+    reg_loss = reg.mean()
+    loss = lam_img * (coarse_loss + fine_loss) + lam_reg * reg_loss
+    loss.backward()
+    psnr = -10. * torch.log10(fine_loss.detach())
+    arrays = dict(coarse=coarse, fine=fine, target=target, reg=reg, lambda_image=lam_img, lambda_regularization=lam_reg,
+                  vmax=1.0, a=0.005, loss=loss, coarse_loss=coarse_loss, fine_loss=fine_loss, reg_loss=reg_loss, psnr=psnr,
+                  g_coarse=coarse.grad, g_fine=fine.grad, g_reg=reg.grad)
+    # optimiser: three tensors, four steps; gradient scales chosen so that steps 0 and 2 clip and 1 and 3 do not
+    shapes = [(64, 84), (64,), (2, 64)]
+    params = [torch.nn.Parameter(torch.randn(sh, generator=g) * 0.1) for sh in shapes]
+    opt = torch.optim.Adam(params, lr=1e-4)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=(1e-5 / 1e-4) ** (1 / 1e6))
+    for i, p in enumerate(params):
+        arrays[f'p0_{i}'] = p.detach().clone()
+    for step, scale in enumerate([1.0, 1e-3, 0.2, 1e-4]):
+        for i, p in enumerate(params):
+            p.grad = torch.randn(p.shape, generator=g) * scale
+            arrays[f'grad{step}_{i}'] = p.grad.clone()
+        total = torch.nn.utils.clip_grad_norm_(params, 0.5)
+        opt.step()
+        if sched.get_last_lr()[0] > 5e-5:
+            sched.step()
+        arrays[f'norm{step}'] = total
+        arrays[f'lr{step + 1}'] = sched.get_last_lr()[0]
+        for i, p in enumerate(params):
+            arrays[f'p{step + 1}_{i}'] = p.detach().clone()
+            arrays[f'clipped{step}_{i}'] = p.grad.clone()
+    npz('g7_train_step', **arrays)
+
+
 if __name__ == '__main__':
-    main()
+    if sys.argv[1:] == ['g7']:
+        torch.manual_seed(7)
+        torch.set_num_threads(1)
+        gen_g7(ref_import.import_reference())
+    else:
+        main()

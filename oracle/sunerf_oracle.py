@@ -268,6 +268,41 @@ def emission_training_loss(outputs: Dict[str, torch.Tensor], target_image: torch
     return {'loss': loss, 'coarse': coarse_loss, 'fine': fine_loss, 'regularization': reg_loss}
 
 
+def clip_grad_norm(grads: List[torch.Tensor], max_norm: float):
+    """torch.nn.utils.clip_grad_norm_ (Lightning's gradient_clip_val, run_emission.py:72): global L2 norm over all
+    tensors, coefficient max_norm / (norm + 1e-6) clamped to 1.  Returns (total_norm, clipped grads)."""
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g) for g in grads]))
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    return total, [g * coef for g in grads]
+
+
+def adam_step(params: List[torch.Tensor], grads: List[torch.Tensor], exp_avg: List[torch.Tensor],
+              exp_avg_sq: List[torch.Tensor], step: int, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8):
+    """torch.optim.Adam (sunerf.py:31; no weight decay / amsgrad), operation order of torch/optim/adam.py's
+    single-tensor path.  ``step`` counts from 1.  Updates the lists in place."""
+    import math
+    beta1, beta2 = betas
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    step_size = lr / bc1
+    bc2_sqrt = math.sqrt(bc2)
+    for i, g in enumerate(grads):
+        exp_avg[i] = exp_avg[i] + (g - exp_avg[i]) * (1 - beta1)
+        exp_avg_sq[i] = exp_avg_sq[i] * beta2 + (1 - beta2) * g * g
+        denom = exp_avg_sq[i].sqrt() / bc2_sqrt + eps
+        params[i] = params[i] + (-step_size) * exp_avg[i] / denom
+
+
+def lr_after(steps: int, start: float = 1e-4, end: float = 1e-5, iterations: float = 1e6, floor: float = 5e-5) -> float:
+    """sunerf.py:32-40: ExponentialLR(gamma = (end / start) ** (1 / iterations)) stepped after every batch while the last
+    learning rate is above ``floor``."""
+    gamma = (end / start) ** (1 / iterations)
+    lr = start
+    for _ in range(steps):
+        if lr > floor:
+            lr = lr * gamma
+    return lr
+
+
 # --------------------------------------------------------------------------------------------------------------
 # synthetic inputs (SURVEY.md section 8d) -- restates data/ray_sampling.py:11-35 and
 # train/coordinate_transformation.py:36-54 without sunpy/astropy

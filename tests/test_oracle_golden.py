@@ -1,6 +1,7 @@
 """Pins the CPU restatement (oracle/sunerf_oracle.py) against golden vectors produced by the REAL reference
 (oracle/gen_golden.py).  Runs on CPU, no GPU needed.  Tolerance: bit-exact wherever the aten op sequence is the
 same; 1e-6 rel otherwise (stated per test)."""
+import numpy as np
 import torch
 
 import sunerf_oracle as orc
@@ -148,3 +149,29 @@ def test_g6_density_temperature_end_to_end():
     close(la_f['171'].grad, g['grad__fine_model__log_absortpion__171'])        # relu(negative) -> zero gradient
     close(fine[0][0].grad, g['grad__fine_model__in_layer__1__weight'])
     close(coarse[-1][1].grad, g['grad__coarse_model__out_layer__bias'])
+
+
+def test_g7_training_loss_and_clip_adam():
+    """Loss section of training_step and 4 clip + Adam steps: restatement vs the torch calls the reference makes."""
+    g = load_golden('g7_train_step')
+    T = lambda k: torch.from_numpy(np.asarray(g[k]))   # noqa: E731
+    coarse, fine, reg = T('coarse').requires_grad_(True), T('fine').requires_grad_(True), T('reg').requires_grad_(True)
+    out = orc.emission_training_loss({'coarse_image': coarse, 'fine_image': fine, 'regularization': reg}, T('target'),
+                                     float(g['lambda_image']), float(g['lambda_regularization']), float(g['vmax']),
+                                     float(g['a']))
+    out['loss'].backward()
+    for k, ref in (('loss', 'loss'), ('coarse', 'coarse_loss'), ('fine', 'fine_loss'), ('regularization', 'reg_loss')):
+        assert abs(out[k].item() - float(g[ref])) <= 1e-6 * abs(float(g[ref])), k
+    for got, ref in ((coarse.grad, 'g_coarse'), (fine.grad, 'g_fine'), (reg.grad, 'g_reg')):
+        close(got, T(ref), 1e-6)
+    params = [T(f'p0_{i}') for i in range(3)]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    for step in range(4):
+        total, clipped = orc.clip_grad_norm([T(f'grad{step}_{i}') for i in range(3)], 0.5)
+        assert abs(total.item() - float(g[f'norm{step}'])) <= 1e-6 * float(g[f'norm{step}'])
+        orc.adam_step(params, clipped, m, v, step + 1, lr=orc.lr_after(step))
+        assert abs(orc.lr_after(step + 1) - float(g[f'lr{step + 1}'])) <= 1e-12
+        for i in range(3):
+            close(clipped[i], T(f"clipped{step}_{i}"), 1e-6)
+            close(params[i], T(f"p{step + 1}_{i}"), 1e-6)
