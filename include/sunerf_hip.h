@@ -168,6 +168,21 @@ int sunerf_dt_integral_bwd(const float* raw, const float* z_vals, const float* r
                            void* g_absmax, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Input side of the path: observer rays on the device.
+ * Replaces get_rays, sunerf/data/ray_sampling.py:7-36, and the host-side tiling / H2D copy of the rays and of the
+ * time column in SuNeRFLoader.render_observer_image, sunerf/evaluation/loader.py:73-92 and :186-214.
+ *   tx, ty   : helioprojective angles [rad], fp64, device.  per_pixel = 0: tx[width] (columns) and ty[rows] (axes of a
+ *              regular grid; pixel p = row * width + column);  per_pixel != 0: tx[p], ty[p] for every pixel of the frame
+ *              (e.g. sunpy's all_coordinates_from_map for a real WCS)
+ *   pixels [pix_begin, pix_begin + n_pix) of the frame are produced (one tile)
+ *   c2w_host : HOST pointer, 12 floats = rows of pose_spherical(...)[:3, :4] (train/coordinate_transformation.py:36-54)
+ *   rays_o, rays_d : [n_pix, 3] out;  times : [n_pix] out, filled with time_value (may be NULL)
+ * ---------------------------------------------------------------------------------------------------------- */
+int sunerf_observer_rays(const double* tx, const double* ty, int per_pixel, int width, int64_t pix_begin, int64_t n_pix,
+                         const float* c2w_host, float time_value, float* rays_o, float* rays_d, float* times,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Output side of the path: training loss and optimiser step without host synchronisation.
  *
  * sunerf_training_loss replaces EmissionSuNeRFModule.training_step's loss section, sunerf/model/sunerf.py:105-125

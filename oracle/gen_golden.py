@@ -18,6 +18,7 @@ Fixtures:
   g7_train_step     loss section of training_step (reference ImageAsinhScaling + nn.MSELoss, sunerf.py:110-122) with
                     its image gradients, and 4 steps of clip_grad_norm_(0.5) + torch.optim.Adam(lr=1e-4) on three
                     tensors (what Lightning 1.9.3's gradient_clip_val + configure_optimizers, sunerf.py:31, execute)
+  g8_observer_rays  pose_spherical (with and without shift) and get_rays on a regular and on a distorted pixel grid
 """
 import os
 import sys
@@ -181,6 +182,7 @@ def main():
     arrays.update({'grad__' + k.replace('.', '__'): p.grad for k, p in dt.named_parameters()})
     npz('g6_dt_e2e', **arrays)
     gen_g7(ref)
+    gen_g8(ref)
     ref_import.release_reference()
 
 
@@ -228,10 +230,50 @@ def gen_g7(ref):
     npz('g7_train_step', **arrays)
 
 
+def gen_g8(ref):
+    """Observer poses and rays: the reference's pose_spherical (coordinate_transformation.py:36-54) and get_rays
+    (data/ray_sampling.py:7-36) on a helioprojective pixel grid with per-pixel distortion (stands in for a real WCS;
+    sunpy is not installed, get_rays only calls ``img_coords.Tx/Ty.to_value(u.rad)``)."""
+    import importlib
+    ct = importlib.import_module('sunerf.train.coordinate_transformation')
+    rs = importlib.import_module('sunerf.data.ray_sampling')
+
+    class _Angle:
+        def __init__(self, a):
+            self.a = a
+
+        def to_value(self, unit):
+            return self.a
+
+    class _Coords:
+        def __init__(self, tx, ty):
+            self.Tx, self.Ty = _Angle(tx), _Angle(ty)
+
+    rng = np.random.default_rng(5)
+    h, w = 9, 13
+    half = 1.1 * 960. / 206264.806
+    ty, tx = np.meshgrid(np.linspace(-half, half, h), np.linspace(-half * 1.3, half * 1.3, w), indexing='ij')
+    tx_d = tx + rng.normal(0, 1e-5, tx.shape)
+    ty_d = ty + rng.normal(0, 1e-5, ty.shape)
+    arrays = dict(tx_axis=tx[0], ty_axis=ty[:, 0], tx_pix=tx_d, ty_pix=ty_d)
+    poses = {'a': (-0.3, 0.1, 215.032, None), 'b': (2.1, -0.7, 50.0, (0.01, -0.02, 0.03))}
+    for name, (theta, phi, radius, shift) in poses.items():
+        c2w = ct.pose_spherical(theta, phi, radius, shift).numpy()
+        arrays[f'pose_{name}'] = np.array([theta, phi, radius] + list(shift or (0., 0., 0.)) + [0. if shift is None else 1.])
+        arrays[f'c2w_{name}'] = c2w
+        for grid, (gx, gy) in (('axis', (tx, ty)), ('pix', (tx_d, ty_d))):
+            o, d = rs.get_rays(_Coords(gx, gy), c2w)
+            arrays[f'rays_o_{name}_{grid}'] = o
+            arrays[f'rays_d_{name}_{grid}'] = d
+    npz('g8_observer_rays', **arrays)
+
+
 if __name__ == '__main__':
-    if sys.argv[1:] == ['g7']:
+    if len(sys.argv) > 1 and all(a in ('g7', 'g8') for a in sys.argv[1:]):
         torch.manual_seed(7)
         torch.set_num_threads(1)
-        gen_g7(ref_import.import_reference())
+        ref = ref_import.import_reference()
+        for a in sys.argv[1:]:
+            {'g7': gen_g7, 'g8': gen_g8}[a](ref)
     else:
         main()

@@ -66,6 +66,7 @@ def _install_stubs():
         units.Mm = _Unit(1e8)
         units.solRad = _Unit(6.957e10)      # IAU 2015 nominal solar radius in cm
         units.K = _Unit(1.0)
+        units.rad = _Unit(1.0)
         astropy.units = units
         sys.modules['astropy'] = astropy
         sys.modules['astropy.units'] = units

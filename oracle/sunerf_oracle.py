@@ -307,16 +307,35 @@ def lr_after(steps: int, start: float = 1e-4, end: float = 1e-5, iterations: flo
 # synthetic inputs -- restates data/ray_sampling.py:11-35 and
 # train/coordinate_transformation.py:36-54 without sunpy/astropy
 # --------------------------------------------------------------------------------------------------------------
-def pose_spherical(theta: float, phi: float, radius: float) -> torch.Tensor:
-    """coordinate_transformation.py:36-54: camera-to-world 4x4 from (lon, lat, radius)."""
+def pose_spherical(theta: float, phi: float, radius: float, shift=None) -> torch.Tensor:
+    """coordinate_transformation.py:36-54: camera-to-world 4x4 from (lon, lat, radius), including the axis permutation of
+    :50 and the optional shift of :51-52."""
     import numpy as np
-    trans_t = torch.tensor([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, radius], [0, 0, 0, 1]], dtype=torch.float32)
-    rot_phi = torch.tensor([[1, 0, 0, 0], [0, np.cos(phi), -np.sin(phi), 0],
-                            [0, np.sin(phi), np.cos(phi), 0], [0, 0, 0, 1]], dtype=torch.float32)
-    rot_theta = torch.tensor([[np.cos(theta), 0, -np.sin(theta), 0], [0, 1, 0, 0],
-                              [np.sin(theta), 0, np.cos(theta), 0], [0, 0, 0, 1]], dtype=torch.float32)
-    c2w = rot_theta @ (rot_phi @ trans_t)
+    T = lambda rows: torch.Tensor(rows).float()   # noqa: E731  (the reference builds its matrices the same way)
+    c2w = T([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    c2w = T([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, radius], [0, 0, 0, 1]]) @ c2w
+    c2w = T([[1, 0, 0, 0], [0, np.cos(phi), -np.sin(phi), 0], [0, np.sin(phi), np.cos(phi), 0], [0, 0, 0, 1]]) @ c2w
+    c2w = T([[np.cos(theta), 0, -np.sin(theta), 0], [0, 1, 0, 0], [np.sin(theta), 0, np.cos(theta), 0], [0, 0, 0, 1]]) @ c2w
+    c2w = T([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]]) @ c2w
+    if shift is not None:
+        tx, ty, tz = shift
+        c2w = T([[1, 0, 0, tx], [0, 1, 0, ty], [0, 0, 1, tz], [0, 0, 0, 1]]) @ c2w
     return c2w
+
+
+def get_rays(Tx, Ty, c2w) -> Tuple[torch.Tensor, torch.Tensor]:
+    """ray_sampling.py:7-36 for helioprojective angles Tx, Ty [rad] (float64 arrays of shape (H, W)): numpy, like the
+    reference.  Returns (H, W, 3) origins and directions as fp32 tensors."""
+    import numpy as np
+    Tx, Ty = np.asarray(Tx, dtype=np.float64), np.asarray(Ty, dtype=np.float64)
+    c2w = np.asarray(c2w, dtype=np.float32)
+    x = np.sin(Tx)
+    y = -np.sin(Ty) * np.cos(Tx)
+    z = -np.cos(Tx) * np.cos(Ty)
+    directions = np.stack([x, y, z], axis=-1, dtype=np.float32)
+    rays_d = np.sum(directions[..., None, :] * c2w[:3, :3], axis=-1)
+    rays_o = np.tile(c2w[None, :3, -1], [rays_d.shape[0], rays_d.shape[1], 1])
+    return torch.from_numpy(rays_o), torch.from_numpy(rays_d)
 
 
 def synthetic_rays(resolution: int, theta: float = -0.3, phi: float = 0.1, radius: float = 215.032,

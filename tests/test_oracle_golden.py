@@ -175,3 +175,19 @@ def test_g7_training_loss_and_clip_adam():
         for i in range(3):
             close(clipped[i], T(f"clipped{step}_{i}"), 1e-6)
             close(params[i], T(f"p{step + 1}_{i}"), 1e-6)
+
+
+def test_g8_pose_and_rays_bit_exact():
+    g = load_golden('g8_observer_rays')
+    for name in ('a', 'b'):
+        theta, phi, radius, sx, sy, sz, has_shift = [float(v) for v in g[f'pose_{name}']]
+        c2w = orc.pose_spherical(theta, phi, radius, (sx, sy, sz) if has_shift else None)
+        exact(c2w, g[f'c2w_{name}'])
+        for grid in ('axis', 'pix'):
+            if grid == 'axis':
+                ty, tx = np.meshgrid(np.asarray(g['ty_axis']), np.asarray(g['tx_axis']), indexing='ij')
+            else:
+                tx, ty = np.asarray(g['tx_pix']), np.asarray(g['ty_pix'])
+            o, d = orc.get_rays(tx, ty, c2w)
+            exact(o, g[f'rays_o_{name}_{grid}'])
+            exact(d, g[f'rays_d_{name}_{grid}'])
