@@ -163,3 +163,29 @@ def test_fit_steps_matches_torch_adam_and_clip():
         # differences of the loss gradients are amplified: max bound looser than the mean bound.)
         d = (p - q).abs()
         assert d.max().item() < 1e-4 and d.mean().item() < 1e-6, (k, d.max().item(), d.mean().item())
+
+
+def test_fit_steps_from_resident_ray_pool(tmp_path):
+    """Reference file formats (rays_batches.npy (P,2,3), times (P,1), images (P,1)) -> RayPool on the device -> fit_steps."""
+    import numpy as np
+    from sunerf.model.sunerf import EmissionSuNeRFModule, fit_steps
+    from sunerf_hip.feed import RayPool, training_batches
+    g = load_golden('g5_emission_e2e')
+    reps = 8
+    rays = torch.stack([g['rays_o'], g['rays_d']], 1).repeat(reps, 1, 1).numpy()
+    paths = {}
+    for k, name, arr in (('rays', 'rays_batches.npy', rays), ('time', 'times_batches.npy', g['times'].repeat(reps, 1).numpy()),
+                         ('target_image', 'images_batches.npy', g['target'].repeat(reps, 1).numpy())):
+        paths[k] = str(tmp_path / name)
+        np.save(paths[k], arr)
+    pool = RayPool.from_files(paths, batch_size=100, device='cuda')
+    assert pool.data['rays'].is_cuda and len(pool) == -(-rays.shape[0] // 100)
+    torch.manual_seed(0)
+    mod = EmissionSuNeRFModule(Rs_per_ds=1.0, seconds_per_dt=1.0, image_scaling_config={'vmax': 1, 'a': 0.005},
+                               sampling_config={'type': 'stratified', 'n_samples': 32, 'perturb': True},
+                               hierarchical_sampling_config={'type': 'hierarchical', 'n_samples': 32},
+                               model_config={'d_filter': 64}, lr_config={'start': 1e-3, 'end': 1e-4, 'iterations': 100}).cuda()
+    losses = fit_steps(mod, training_batches(pool, 2 * len(pool) + 1))
+    assert len(losses) == 2 * len(pool) + 1 and pool.epoch == 3
+    assert torch.isfinite(torch.stack(losses)).all()
+    assert torch.stack(losses[-5:]).mean().item() < torch.stack(losses[:5]).mean().item()
