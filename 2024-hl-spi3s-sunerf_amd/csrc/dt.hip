@@ -258,6 +258,57 @@ int check_common(const DtArgs& a) {
 
 }  // namespace
 
+namespace {
+
+// SimpleStar.forward, sunerf/model/stellar_model.py:53-102 (Pascoe et al. 2019 eq. 4 and 6), at the sample points
+// o + d z of sampling.py:100: the analytic density / temperature field that stands in for a trained NeRF_DT when synthetic
+// observations are rendered (evaluation/image_render.py:236-268).  raw = (ln rho, log10 T).
+struct StarArgs {
+  const float* rays_o; const float* rays_d; const float* z_vals;
+  int64_t n_rays; int S;
+  float rho_0, h0, T0, Rs, t_photosphere;
+  float* raw;
+};
+
+__global__ __launch_bounds__(256) void simple_star_kernel(StarArgs a) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.n_rays * a.S) return;
+  const int64_t ray = idx / a.S;
+  const float z = a.z_vals[idx];
+  const float x = a.rays_o[ray * 3 + 0] + a.rays_d[ray * 3 + 0] * z;
+  const float y = a.rays_o[ray * 3 + 1] + a.rays_d[ray * 3 + 1] * z;
+  const float w = a.rays_o[ray * 3 + 2] + a.rays_d[ray * 3 + 2] * z;
+  const float radius = sqrtf((x * x + y * y) + w * w);
+  float rho = a.rho_0, temp = a.t_photosphere;
+  if (radius > 1.f) {
+    rho = a.rho_0 * expf((1.f / a.h0) * (1.f / radius - 1.f));
+    temp = radius <= a.Rs ? (radius - 1.f) * ((a.T0 - a.t_photosphere) / (a.Rs - 1.f)) + a.t_photosphere : a.T0;
+  }
+  // a NaN radius (missed-sphere rays of SphericalSampler) fails every comparison of the reference's masks and leaves the
+  // zero-initialised rho / temp: log(0) = -inf
+  if (!(radius == radius)) { rho = 0.f; temp = 0.f; }
+  a.raw[idx * 2 + 0] = logf(rho);
+  a.raw[idx * 2 + 1] = log10f(temp);
+}
+
+}  // namespace
+
+extern "C" int sunerf_simple_star_field(const float* rays_o, const float* rays_d, const float* z_vals, int64_t n_rays,
+                                        int n_samples, float rho_0, float h0, float T0, float Rs, float t_photosphere,
+                                        float* raw, void* stream) {
+  if (n_rays < 0 || n_samples < 1) return SUNERF_E_BADARG;
+  if (n_rays == 0) return 0;
+  if (!rays_o || !rays_d || !z_vals || !raw) return SUNERF_E_BADARG;
+  StarArgs a;
+  a.rays_o = rays_o; a.rays_d = rays_d; a.z_vals = z_vals; a.n_rays = n_rays; a.S = n_samples;
+  a.rho_0 = rho_0; a.h0 = h0; a.T0 = T0; a.Rs = Rs; a.t_photosphere = t_photosphere; a.raw = raw;
+  const int64_t total = n_rays * n_samples;
+  SUNERF_CLEAR_ERROR();
+  hipLaunchKernelGGL(simple_star_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  SUNERF_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int sunerf_dt_integral_fwd(const float* raw, const float* z_vals, const float* rays_o, const float* rays_d,
                                       const float* wavelengths, int n_wavelengths, const float* table_logt,
                                       const float* table_resp, const float* log_abs, const float* vol_c, float base_log_density,

@@ -36,6 +36,9 @@ class PositionalEncoding(nn.Module):
 
 class NeRF(nn.Module):
     """model.py:7-57."""
+    # class-level defaults: a NeRF unpickled from a reference-written .snf (sunerf.py:62-74) carries neither attribute
+    _packed = None
+    _packed_key = None
 
     def __init__(self, d_input: int = 4, d_output: int = 2, n_layers: int = 8, d_filter: int = 512,
                  skip: Tuple[int] = (), encoding='positional'):
@@ -74,8 +77,8 @@ class NeRF(nn.Module):
 
     def __getstate__(self):  # the packed image is a cache, not state (save_state pickles the module, sunerf.py:62-74)
         st = self.__dict__.copy()
-        st['_packed'] = None
-        st['_packed_key'] = None
+        st.pop('_packed', None)
+        st.pop('_packed_key', None)
         return st
 
     def forward(self, x: torch.Tensor):

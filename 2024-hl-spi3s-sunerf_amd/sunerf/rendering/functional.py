@@ -126,6 +126,16 @@ class _DtPass(torch.autograd.Function):
 
 def dt_pass(model, tables, pixel_factor, rays_o, rays_d, times, z_vals, wavelengths, reg_radius, want_epilogues):
     """Dict of one DT pass' outputs (image (N,W), weights, regularizing_quantity[, maps, regularization])."""
+    if hasattr(model, 'field_on_rays'):
+        # analytic field (SimpleStar) instead of an MLP: same integral, inference only (stellar_model.py, image_render.py:266)
+        with torch.no_grad():
+            raw = model.field_on_rays(rays_o, rays_d, z_vals)
+            la = torch.stack([model.log_absortpion[str(w)].detach() for w in ops.AIA_WAVELENGTHS])
+            out = ops.dt_integral_fwd(raw, z_vals, rays_o, rays_d, wavelengths, tables[0], tables[1], la,
+                                      model.volumetric_constant, model.base_log_density, model.base_log_temperature,
+                                      pixel_factor, reg_radius, want_epilogues=want_epilogues)
+        out['regularizing_quantity'] = out.pop('reg_q')
+        return out
     la = [model.log_absortpion[str(w)] for w in ops.AIA_WAVELENGTHS]
     mlp_params = []
     for lin in model.linears():

@@ -16,6 +16,12 @@ def _points(rays_o, rays_d, z_vals):
 
 class _RaySampler(nn.Module):
     kind = None
+    _scalars = None      # class-level default: instances unpickled from a reference-written .snf have no such attribute
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop('_scalars', None)      # a cache, not state
+        return state
 
     def __init__(self, Rs_per_ds, distance, n_samples, perturb):
         super().__init__()
@@ -71,6 +77,12 @@ class SphericalSampler(_RaySampler):
 
 class HierarchicalSampler(nn.Module):
     """sampling.py:104-169: inverse-CDF resampling of the coarse weights, merged with the coarse samples."""
+    _u = None            # class-level default (see _RaySampler)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop('_u', None)
+        return state
 
     def __init__(self, n_samples=128, perturb=False):
         super().__init__()

@@ -58,6 +58,9 @@ _SIGNATURES = {
                                              ctypes.c_int, c_f32p, c_f32p, c_void]),
     'sunerf_observer_rays': (ctypes.c_int, [c_void, c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                              ctypes.POINTER(ctypes.c_float), ctypes.c_float, c_f32p, c_f32p, c_f32p, c_void]),
+    'sunerf_simple_star_field': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
+                                                 ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_f32p,
+                                                 c_void]),
     'sunerf_train_workspace_bytes': (ctypes.c_size_t, []),
     'sunerf_training_loss': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int64, c_f32p, ctypes.c_int64,
                                              ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), ctypes.c_int,

@@ -270,6 +270,18 @@ def dt_integral_fwd(raw, z_vals, rays_o, rays_d, wavelengths, table_logt, table_
     return out
 
 
+def simple_star_field(rays_o, rays_d, z_vals, rho_0: float, h0: float, T0: float, Rs: float, t_photosphere: float):
+    """SimpleStar.forward (stellar_model.py:53-102) at the sample points of every ray -> raw (N, S, 2) = (ln rho, log10 T)."""
+    lib = _l.load()
+    n, s = z_vals.shape
+    rays_o = _dev(rays_o, 'rays_o', (n, 3)); rays_d = _dev(rays_d, 'rays_d', (n, 3)); z_vals = _dev(z_vals, 'z_vals', (n, s))
+    raw = torch.empty(n, s, 2, dtype=torch.float32, device=z_vals.device)
+    st = lib.sunerf_simple_star_field(_ptr(rays_o), _ptr(rays_d), _ptr(z_vals), n, s, float(rho_0), float(h0), float(T0),
+                                      float(Rs), float(t_photosphere), _ptr(raw), _stream(z_vals.device))
+    _l.check(st, 'sunerf_simple_star_field')
+    return raw
+
+
 def dt_integral_bwd(raw, z_vals, rays_o, rays_d, wavelengths, table_logt, table_resp, log_abs, vol_c, base_log_density,
                     base_log_temperature, pixel_intensity_factor, reg_radius, g_image, g_reg):
     """-> (g_raw (N,S,2), g_log_abs (7,), g_vol_c (1,), absmax)."""

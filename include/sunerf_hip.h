@@ -218,6 +218,16 @@ int sunerf_clip_adam_step(float* params, float* grads, float* exp_avg, float* ex
                           void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Analytic field of SimpleStar: replaces SimpleStar.forward, sunerf/model/stellar_model.py:53-102,
+ * evaluated at the sample points o + d z (sampling.py:100) of every ray; the result feeds sunerf_dt_integral_fwd with
+ * base_log_density = base_log_temperature = 0 exactly as the MLP output of NeRF_DT does
+ * (DensityTemperatureRadiativeTransfer(model=SimpleStar), evaluation/image_render.py:266-268).
+ *   raw [N, S, 2] out: (ln rho, log10 T);  rho_0 [cm^-3], h0 and Rs [solar radii], T0 and t_photosphere [K]
+ * ---------------------------------------------------------------------------------------------------------- */
+int sunerf_simple_star_field(const float* rays_o, const float* rays_d, const float* z_vals, int64_t n_rays, int n_samples,
+                             float rho_0, float h0, float T0, float Rs, float t_photosphere, float* raw, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Hierarchical (inverse-CDF) resampling + merge.
  * Replaces HierarchicalSampler.forward / sample_pdf, sampling.py:111-169 (perturb=False: u = linspace(0,1,S_f),
  * passed in as the tensor `u` [S_f] so that torch.linspace's own fp32 values are used; or a per-ray u [N,S_f]

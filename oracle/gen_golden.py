@@ -19,6 +19,10 @@ Fixtures:
                     its image gradients, and 4 steps of clip_grad_norm_(0.5) + torch.optim.Adam(lr=1e-4) on three
                     tensors (what Lightning 1.9.3's gradient_clip_val + configure_optimizers, sunerf.py:31, execute)
   g8_observer_rays  pose_spherical (with and without shift) and get_rays on a regular and on a distorted pixel grid
+  g9_simple_star    SimpleStar.forward on 400 points and DensityTemperatureRadiativeTransfer(model=SimpleStar) two-pass
+                    forward ("Interp1D restated" like g6)
+  g10_reference_state  a .snf written from the reference's own classes (pickled rendering module + data config) and the
+                    outputs the reference renders from those weights
 """
 import os
 import sys
@@ -183,6 +187,8 @@ def main():
     npz('g6_dt_e2e', **arrays)
     gen_g7(ref)
     gen_g8(ref)
+    gen_g9(ref)
+    gen_g10(ref)
     ref_import.release_reference()
 
 
@@ -268,12 +274,89 @@ def gen_g8(ref):
     npz('g8_observer_rays', **arrays)
 
 
+def gen_g9(ref):
+    """SimpleStar (stellar_model.py) on points inside / in the ramp / outside, and the two-pass DT render of
+    DensityTemperatureRadiativeTransfer(model=SimpleStar) as evaluation/image_render.py:266-268 builds it."""
+    import importlib
+    sm = importlib.import_module('sunerf.model.stellar_model')
+    DT = importlib.import_module('sunerf.rendering.density_temperature').DensityTemperatureRadiativeTransfer
+    star = sm.SimpleStar()
+    g = torch.Generator().manual_seed(9)
+    dirs = torch.randn(400, 3, generator=g)
+    dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+    radii = torch.cat([torch.rand(100, generator=g), 1 + 0.02 * torch.rand(100, generator=g),
+                       1.02 + 0.5 * torch.rand(198, generator=g), torch.tensor([1.0, 1.02])])
+    pts = torch.cat([dirs * radii[:, None], torch.rand(400, 1, generator=g)], -1)
+    with torch.no_grad():
+        out = star(pts)
+    arrays = dict(points=pts, inferences=out['inferences'], t_photosphere=star.t_photosphere)
+    arrays.update({'sp__' + k: v for k, v in star.stellar_parameters.items()})
+    arrays.update({'la__' + k: v for k, v in star.log_absortpion.items()})
+    cwd = os.getcwd()
+    os.chdir(ref_import.REFERENCE_ROOT)          # density_temperature.py:131 reads the response table relative to cwd
+    try:
+        dt = DT(Rs_per_ds=1, model=sm.SimpleStar, model_config={}, device=torch.device('cpu'),
+                sampling_config={'type': 'stratified', 'n_samples': 24, 'perturb': False},
+                hierarchical_sampling_config={'type': 'hierarchical', 'n_samples': 24})
+    finally:
+        os.chdir(cwd)
+    # the default absorption scalars (~20) make the corona opaque within the first sample (every image is exactly 0);
+    # optical depths of order one need kappa ~ 1 / (rho_0 * path) ~ 1e-9
+    with torch.no_grad():
+        for m in (dt.coarse_model, dt.fine_model):
+            for i, w in enumerate(orc.AIA_WAVELENGTHS):
+                m.log_absortpion[str(w)].fill_((1 + i) * 1e-9)
+            m.volumetric_constant.fill_(0.7)
+    o, d = orc.synthetic_rays(6)                    # unit directions: monotonic z along the line of sight
+    t = torch.rand(o.shape[0], 1, generator=g)
+    wl = torch.tensor([[94., 131., 171., 193., 211., 304., 335.]]).repeat(o.shape[0], 1)
+    wl[2:5, 1] = 0.
+    with torch.no_grad():
+        outputs = dt(o, d, t, wl)
+    arrays.update({'la__' + k: v for k, v in dt.fine_model.log_absortpion.items()})
+    logte, tresp = orc.read_aia_response_genx(os.path.join(ref_import.REFERENCE_ROOT, 'sunerf/data/aia_temp_resp.genx'))
+    arrays.update(rays_o=o, rays_d=d, times=t, wavelengths=wl, t_vals=dt.sampler.t_vals, aia_logte=logte, aia_tresp=tresp,
+                  aia_exp_time=2.9, pixel_intensity_factor=1e10, vol_c=dt.fine_model.volumetric_constant)
+    arrays.update({'out__' + k: v for k, v in outputs.items()})
+    npz('g9_simple_star', **arrays)
+
+
+def gen_g10(ref):
+    """A ``.snf`` state file as the reference's save_state writes it (sunerf.py:62-74): the pickled rendering module built
+    from the reference's own classes + data configuration, and what the (shimmed) reference renders from those weights.
+    Lets the loader mirror prove that reference-trained states load into the fused classes."""
+    import datetime
+    import importlib
+    Emission = importlib.import_module('sunerf.rendering.emission').EmissionRadiativeTransfer
+    torch.manual_seed(21)
+    cfg = dict(Rs_per_ds=1.0, sampling_config={'type': 'stratified', 'n_samples': 16, 'perturb': False},
+               hierarchical_sampling_config={'type': 'hierarchical', 'n_samples': 16}, model_config={'d_filter': 64})
+    plain = Emission(**{k: (dict(v) if isinstance(v, dict) else v) for k, v in cfg.items()})
+    state = {'rendering': plain,
+             'data_config': {'type': 'emission', 'Rs_per_ds': 1.0, 'seconds_per_dt': 86400., 'wavelength': 193,
+                             'ref_time': datetime.datetime(2022, 3, 1), 'resolution': (12, 12),
+                             'wcs': {'shape': (12, 12), 'cdelt': (200., 200.)},
+                             'times': [datetime.datetime(2022, 3, 1), datetime.datetime(2022, 3, 5)], 'cmap': 'gray'},
+             'Rs_per_ds': 1.0, 'seconds_per_dt': 86400., 'ref_time': datetime.datetime(2022, 3, 1)}
+    torch.save(state, os.path.join(OUT, 'g10_reference_state.snf'))
+    shim = ref_import.shimmed_emission_class()(**{k: (dict(v) if isinstance(v, dict) else v) for k, v in cfg.items()})
+    shim.load_state_dict(plain.state_dict())
+    o, d, t = test_rays(5, seed=6)
+    with torch.no_grad():
+        outputs = shim(o, d, t)
+        pts = torch.rand(33, 4, generator=torch.Generator().manual_seed(1)) * 2 - 1
+        inf = plain.fine_model(pts)['inferences']
+    arrays = dict(rays_o=o, rays_d=d, times=t, points=pts, inferences=inf)
+    arrays.update({'out__' + k: v for k, v in outputs.items()})
+    npz('g10_reference_state', **arrays)
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and all(a in ('g7', 'g8') for a in sys.argv[1:]):
+    if len(sys.argv) > 1 and all(a in ('g7', 'g8', 'g9', 'g10') for a in sys.argv[1:]):
         torch.manual_seed(7)
         torch.set_num_threads(1)
         ref = ref_import.import_reference()
         for a in sys.argv[1:]:
-            {'g7': gen_g7, 'g8': gen_g8}[a](ref)
+            {'g7': gen_g7, 'g8': gen_g8, 'g9': gen_g9, 'g10': gen_g10}[a](ref)
     else:
         main()

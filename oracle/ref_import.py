@@ -53,9 +53,13 @@ class _Quantity:
         q._unit = unit
         return q
 
+    def __truediv__(self, o):                       # (1 / u.cm) / u.cm, stellar_model.py:33
+        return _Quantity(self.base / (o.scale if isinstance(o, _Unit) else o))
+
     @property
     def value(self):
-        return self.base / getattr(self, '_unit', _Unit()).scale
+        unit = getattr(self, '_unit', _Unit())
+        return self.base / (unit.base if isinstance(unit, _Quantity) else unit.scale)
 
 
 def _install_stubs():

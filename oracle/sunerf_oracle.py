@@ -436,6 +436,50 @@ def render_pass_dt(params: Params, log_abs, vol_c, rays_o, rays_d, times, z_vals
     return out
 
 
+def simple_star_field(query_points: torch.Tensor, rho_0, h0, T0, Rs, t_photosphere: float = 5777.) -> torch.Tensor:
+    """SimpleStar.forward, stellar_model.py:53-102: (M, >=3) points -> (M, 2) = (ln rho, log10 T).  ``rho_0, h0, T0, Rs``
+    are the fp32 ``stellar_parameters`` (0-dim tensors or floats)."""
+    f = lambda v: torch.as_tensor(v, dtype=torch.float32)   # noqa: E731
+    rho_0, h0, T0, Rs = f(rho_0), f(h0), f(T0), f(Rs)
+    x, y, z = query_points[:, 0], query_points[:, 1], query_points[:, 2]
+    radius = torch.sqrt(x ** 2 + y ** 2 + z ** 2)
+    rho = torch.zeros_like(radius)
+    temp = torch.zeros_like(radius)
+    inner, outer = radius <= 1.0, radius > 1.0
+    rho[inner] = rho_0
+    rho[outer] = rho_0 * torch.exp(1 / h0 * (1 / radius[outer] - 1))
+    rho = torch.log(rho)
+    temp[inner] = t_photosphere
+    ramp = torch.logical_and(radius > 1, radius <= Rs)
+    temp[ramp] = (radius[ramp] - 1) * ((T0 - t_photosphere) / (Rs - 1)) + t_photosphere
+    temp[radius > Rs] = T0
+    return torch.stack((rho, torch.log10(temp)), dim=-1)
+
+
+def render_dt_analytic(field, log_abs, vol_c, rays_o, rays_d, wavelengths, logte, resp, *, Rs_per_ds=1., n_coarse=64,
+                       n_fine=128, distance=1.3, pixel_intensity_factor=1e10, t_vals=None) -> Dict[str, torch.Tensor]:
+    """SuNeRFRendering.forward for DensityTemperatureRadiativeTransfer(model=SimpleStar) (image_render.py:266-268):
+    ``field`` maps (M, 3) points to (M, 2) inferences and plays both the coarse and the fine model."""
+    t_vals = linspace_t_vals(n_coarse) if t_vals is None else t_vals
+    z_vals = stratified_z(rays_o, rays_d, t_vals, torch.tensor(distance / Rs_per_ds, dtype=torch.float32),
+                          torch.tensor(1 / Rs_per_ds, dtype=torch.float32))
+
+    def one_pass(z):
+        pts = points_on_rays(rays_o, rays_d, z)
+        inferences = field(pts.reshape(-1, 3)).reshape(*pts.shape[:-1], 2)
+        out = dt_integral(inferences, log_abs, vol_c, z, wavelengths, logte, resp, pixel_intensity_factor)
+        out['points'] = pts
+        return out
+    c = one_pass(z_vals)
+    new_z, z_comb = hierarchical_z(z_vals, c['weights'], n_fine)
+    f = one_pass(z_comb)
+    q = f['regularizing_quantity']
+    dist_pts = f['points'].pow(2).sum(-1).pow(0.5)
+    return {'z_vals_stratified': z_vals, 'coarse_image': c['image'], 'z_vals_hierarchical': new_z, 'fine_image': f['image'],
+            'image': f['image'], 'height_map': (f['weights'] * dist_pts).sum(-1), 'absorption_map': (1 - q).sum(-1),
+            'regularization': torch.relu(dist_pts - 1.25 / Rs_per_ds) * torch.relu(q)}
+
+
 def render_dt(coarse: Params, fine: Params, log_abs_c, vol_c_c, log_abs_f, vol_c_f, rays_o, rays_d, times, wavelengths,
               logte, resp, *, Rs_per_ds=1., n_coarse=64, n_fine=128, distance=1.3, pixel_intensity_factor=1e10,
               t_vals=None) -> Dict[str, torch.Tensor]:

@@ -68,3 +68,38 @@ def test_dt_training_step_gradients():
             continue
         err = ((got - ref).norm() / ref.norm()).item()
         assert err < (3e-3 if name.startswith('fine') else 1e-3), (name, err)
+
+
+def test_simple_star_field_and_render_match_reference():
+    """SimpleStar (analytic field) behind the DT integral: the model mirror's forward on points and the two-pass render of
+    DensityTemperatureRadiativeTransfer(model=SimpleStar) (evaluation/image_render.py:266-268) vs golden g9."""
+    from sunerf.model.stellar_model import SimpleStar
+    from sunerf.rendering.density_temperature import DensityTemperatureRadiativeTransfer
+    g = load_golden('g9_simple_star')
+    star = SimpleStar().cuda()
+    # defaults reproduce the reference's unit conversions (60 Mm -> solar radii, ...)
+    for k in ('Rs', 'h0', 'T0', 'rho_0'):
+        assert torch.equal(star.stellar_parameters[k].cpu(), g['sp__' + k]), k
+    out = star(g['points'].cuda())
+    assert set(out) == {'inferences', 'log_abs', 'vol_c'}
+    # ln rho ~ 19.5 and log10 T ~ 3.8 .. 6.1: device expf / logf / log10f vs glibc within a few ulp
+    assert (out['inferences'].cpu() - g['inferences']).abs().max().item() < 1e-5
+    mod = DensityTemperatureRadiativeTransfer(
+        Rs_per_ds=1, model=SimpleStar, model_config={},
+        sampling_config={'type': 'stratified', 'n_samples': 24, 'perturb': False},
+        hierarchical_sampling_config={'type': 'hierarchical', 'n_samples': 24},
+        response_table=(g['aia_logte'].numpy(), g['aia_tresp'].numpy())).cuda()
+    assert set(k.split('.')[1] for k in mod.state_dict() if k.startswith('fine_model')) == {
+        'volumetric_constant', 'log_absortpion', 'stellar_parameters'}
+    with torch.no_grad():       # g9 renders with absorption scalars of order 1e-9 (optical depths of order one)
+        for m in (mod.coarse_model, mod.fine_model):
+            for w in (94, 131, 171, 193, 211, 304, 335):
+                m.log_absortpion[str(w)].copy_(g[f'la__{w}'])
+            m.volumetric_constant.copy_(g['vol_c'])
+    got = mod(g['rays_o'].cuda(), g['rays_d'].cuda(), g['times'].cuda(), g['wavelengths'].cuda())
+    assert torch.equal(got['z_vals_stratified'].cpu(), g['out__z_vals_stratified'])
+    assert rel(got['coarse_image'], g['out__coarse_image']) < 1e-4
+    assert (got['z_vals_hierarchical'].cpu() - g['out__z_vals_hierarchical']).abs().max().item() < 2e-4
+    for k in ('fine_image', 'image', 'height_map', 'absorption_map', 'regularization'):
+        assert rel(got[k], g['out__' + k]) < 2e-4, k
+    assert (got['image'].cpu()[g['wavelengths'] == 0] == 0).all()

@@ -135,3 +135,30 @@ def test_sunerf_loader_roundtrip(tmp_path):
     want = orc.mlp_forward(orc.params_from_state_dict(sd, 'fine_model.'), torch.from_numpy(pts).reshape(-1, 4))
     assert got.shape == (5, 7, 2)
     assert np.abs(got.reshape(-1, 2) - want.numpy()).max() < 1e-4 * np.abs(want.numpy()).max()
+
+
+def test_reference_written_state_file_loads_into_fused_classes():
+    """A .snf pickled from the REFERENCE's classes (golden g10; sunerf.py:62-74) unpickles into the mirrored classes, and
+    the fused path renders from it what the reference renders from the same weights."""
+    import os
+    from conftest import GOLDEN as GOLDEN_DIR
+    from sunerf.evaluation.loader import SuNeRFLoader
+    from sunerf.rendering.emission import EmissionRadiativeTransfer
+    g = load_golden('g10_reference_state')
+    loader = SuNeRFLoader(os.path.join(GOLDEN_DIR, 'g10_reference_state.snf'), device='cuda')
+    assert type(loader.rendering) is EmissionRadiativeTransfer and loader.wavelength == 193
+    with torch.no_grad():
+        out = loader.rendering(g['rays_o'].cuda(), g['rays_d'].cuda(), g['times'].cuda())
+    assert torch.equal(out['z_vals_stratified'].cpu(), g['out__z_vals_stratified'])
+    for k in ('coarse_image', 'fine_image', 'image', 'height_map', 'absorption_map', 'regularization'):
+        ref = g['out__' + k]
+        err = (out[k].cpu() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-4, (k, err)
+    got = loader.load_coords(g['points'].numpy())
+    assert np.abs(got - g['inferences'].numpy()).max() < 1e-4 * np.abs(g['inferences'].numpy()).max()
+    frame = loader.render_observer_image(lat=0.0, lon=0.2, time=datetime.datetime(2022, 3, 2))
+    assert frame['image'].shape == (12, 12, 1) and np.isfinite(frame['image']).all()
+    # and back: the state dict of the loaded module has exactly the reference's keys
+    keys = set(loader.rendering.state_dict())
+    assert {'sampler.distance', 'sampler.solar_R', 'sampler.t_vals', 'coarse_model.in_layer.0.freq_bands',
+            'fine_model.out_layer.bias'} <= keys

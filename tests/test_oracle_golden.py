@@ -191,3 +191,19 @@ def test_g8_pose_and_rays_bit_exact():
             o, d = orc.get_rays(tx, ty, c2w)
             exact(o, g[f'rays_o_{name}_{grid}'])
             exact(d, g[f'rays_d_{name}_{grid}'])
+
+
+def test_g9_simple_star_field_and_render():
+    """SimpleStar (stellar_model.py:53-102) and the DT render around it vs the reference's own run."""
+    g = load_golden('g9_simple_star')
+    sp = {k: g['sp__' + k] for k in ('rho_0', 'h0', 'T0', 'Rs')}
+    field = lambda p: orc.simple_star_field(p, sp['rho_0'], sp['h0'], sp['T0'], sp['Rs'], float(g['t_photosphere']))  # noqa: E731
+    exact(field(g['points']), g['inferences'])
+    la = {str(w): g[f'la__{w}'] for w in orc.AIA_WAVELENGTHS}
+    resp = (g['aia_tresp'] * float(g['aia_exp_time'])).float()
+    out = orc.render_dt_analytic(field, la, g['vol_c'], g['rays_o'], g['rays_d'], g['wavelengths'], g['aia_logte'].float(),
+                                 resp, n_coarse=24, n_fine=24, pixel_intensity_factor=float(g['pixel_intensity_factor']),
+                                 t_vals=g['t_vals'])
+    for k in ['z_vals_stratified', 'coarse_image', 'z_vals_hierarchical', 'fine_image', 'image', 'height_map',
+              'absorption_map', 'regularization']:
+        exact(out[k], g['out__' + k])
