@@ -16,6 +16,7 @@
 #include "weight_ring.h"
 #include "../../include/sunerf_hip.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -44,6 +45,26 @@ struct RenderArgs {
   char* stash;
   char* scratch;   // d_filter = 512: per-wave activation scratch, gridDim.x * 4 waves * (D/16) * 2 KiB
 };
+
+// Stash and scratch traffic goes through BUFFER instructions: wave-uniform base in a scalar resource descriptor, the lane
+// part (lane * 16) as the one VGPR offset, the many constant fragment offsets as scalar offsets / immediates.  With per-lane
+// 64-bit pointers the compiler materialises one VGPR pair per fragment address, hoists them all out of the chunk loop and
+// spills them (200 spilled VGPRs at d = 512).
+using Rsrc = __amdgpu_buffer_rsrc_t;
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned lane_off() { return (threadIdx.x & 63u) * 16u; }
+__device__ __forceinline__ Rsrc make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_store(half8 v, Rsrc r, int off) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)lane_off(), off, 0);
+}
+__device__ __forceinline__ void buf_store_nt(half8 v, Rsrc r, int off) {   // non-temporal: written once, read by another kernel
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)lane_off(), off, 2);
+}
+__device__ __forceinline__ half8 buf_load(Rsrc r, int off) {
+  return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off(), off, 0));
+}
 
 __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -147,7 +168,7 @@ __device__ __forceinline__ void epi_stage_b(PairTmp& t) {
 // ([fragment][hi 1 KiB | lo 1 KiB]) instead of staying in registers; they come back as the next layer's input.
 template <bool STASH, bool SPILL_OUT>
 __device__ __forceinline__ void epi_stage_c(const PairTmp& t, int p, half8& hi0, half8& lo0, half8& hi1, half8& lo1,
-                                            half8& ch0, half8& ch1, char* st, int cos_delta, char* sc) {
+                                            half8& ch0, half8& ch1, Rsrc st, int st_off, int cos_delta, Rsrc sc, int sc_off) {
   half2v lo;
   lo[0] = (_Float16)t.r0; lo[1] = (_Float16)t.r1;
   if (p < 4) { hi0[2 * p] = t.hi[0]; hi0[2 * p + 1] = t.hi[1]; lo0[2 * p] = lo[0]; lo0[2 * p + 1] = lo[1]; }
@@ -158,14 +179,14 @@ __device__ __forceinline__ void epi_stage_c(const PairTmp& t, int p, half8& hi0,
   }
   // (pinning after every insertion instead makes hipcc rewrite the whole 4-dword tuple each time: measured worse)
   if (p == 3) {
-    if (SPILL_OUT) { *(half8*)sc = hi0; *(half8*)(sc + 1024) = lo0; }
+    if (SPILL_OUT) { buf_store(hi0, sc, sc_off); buf_store(lo0, sc, sc_off + 1024); }
     else { pin_agpr(hi0); pin_agpr(lo0); }
-    if (STASH) { __builtin_nontemporal_store(hi0, (half8*)st); __builtin_nontemporal_store(ch0, (half8*)(st + cos_delta)); }
+    if (STASH) { buf_store_nt(hi0, st, st_off); buf_store_nt(ch0, st, st_off + cos_delta); }
   }
   if (p == 7) {
-    if (SPILL_OUT) { *(half8*)(sc + 2048) = hi1; *(half8*)(sc + 3072) = lo1; }
+    if (SPILL_OUT) { buf_store(hi1, sc, sc_off + 2048); buf_store(lo1, sc, sc_off + 3072); }
     else { pin_agpr(hi1); pin_agpr(lo1); }
-    if (STASH) { __builtin_nontemporal_store(hi1, (half8*)(st + 1024)); __builtin_nontemporal_store(ch1, (half8*)(st + 1024 + cos_delta)); }
+    if (STASH) { buf_store_nt(hi1, st, st_off + 1024); buf_store_nt(ch1, st, st_off + 1024 + cos_delta); }
   }
 }
 
@@ -177,6 +198,14 @@ __device__ __forceinline__ f32x16 bias_tile(const float* bias, int h) {
     acc[4 * j + 0] = b[0]; acc[4 * j + 1] = b[1]; acc[4 * j + 2] = b[2]; acc[4 * j + 3] = b[3];
   }
   return acc;
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
 }
 
 // The MLP as ONE software pipeline over k-steps that runs across tiles, layers, chunks and rays: the A fragments
@@ -257,7 +286,7 @@ struct Mlp {
   template <int KIN, int T0, bool HAS_PREV, int RS0, bool STASH, bool SPILL_OUT = false, bool RELOAD = false>
   static __device__ __forceinline__ f32x16 tile(Ring<D>& ring, Pipe& p, f32x16 acc, half8* xhi, half8* xlo,
                                                 const f32x16& prev, half8& yh0, half8& yl0, half8& yh1, half8& yl1,
-                                                char* st, int cos_delta, char* sc_out = nullptr, const char* sc_in = nullptr) {
+                                                Rsrc st, int st_off, int cos_delta, Rsrc sc, int sc_out_off = 0) {
     // k-steps that carry epilogue micro-ops.  For the first tile of a layer the epilogue produces the layer's own last
     // two input fragments (read by k-steps KIN-2 and KIN-1), so it must be complete before k-step KIN-2.
     constexpr int EPI_STEPS = (KIN - 2) >= 8 ? 8 : (KIN - 2);
@@ -290,11 +319,11 @@ struct Mlp {
       if (HAS_PREV) {
 #pragma unroll
         for (int q = 0; q < PER; ++q)
-          if (s * PER + q < 8) epi_stage_c<STASH, SPILL_OUT>(t[q], s * PER + q, yh0, yl0, yh1, yl1, ch0, ch1, st, cos_delta, sc_out);
+          if (s * PER + q < 8) epi_stage_c<STASH, SPILL_OUT>(t[q], s * PER + q, yh0, yl0, yh1, yl1, ch0, ch1, st, st_off, cos_delta, sc, sc_out_off);
       }
       if (RELOAD && s < KIN - 2) {   // fragments KIN-2, KIN-1 arrive through the carry epilogue of the next layer's first tile
-        xhi[s] = *(const half8*)(sc_in + s * 2048);
-        xlo[s] = *(const half8*)(sc_in + s * 2048 + 1024);
+        xhi[s] = buf_load(sc, s * 2048);
+        xlo[s] = buf_load(sc, s * 2048 + 1024);
         pin_agpr(xhi[s]); pin_agpr(xlo[s]);
       }
       {
@@ -331,12 +360,31 @@ struct Mlp {
   // st_prev / st_own: this lane's stash address of fragment 0 of the previous / of this layer's H block (training).
   template <int KIN, bool HAS_CARRY, int RSL0, bool STASH>
   static __device__ __forceinline__ f32x16 layer(Ring<D>& ring, Pipe& p, const float* bias, int h, half8* xhi, half8* xlo,
-                                                 half8* yhi, half8* ylo, const f32x16& carry, char* st_prev, char* st_own,
-                                                 char* scratch = nullptr) {
+                                                 half8* yhi, half8* ylo, const f32x16& carry, Rsrc st, int st_prev, int st_own,
+                                                 Rsrc scratch) {
     f32x16 prev = carry;
     constexpr int CD = KS * 1024;
     constexpr int XL = 2 * NT - 2;   // previous layer's last tile -> our X fragments
     half8 th0, tl0, th1, tl1;        // SPILL: staging of the fragments that go to scratch
+    if constexpr (SPILL) {
+      // 16 tiles: a `#pragma unroll` loop over a 16-way `if (U == UU)` dispatch exceeds the unroller's size limit and would
+      // stay a run-time loop; compile-time recursion instead
+      static_for<0, NT>([&](auto uu) {
+        constexpr int UU = decltype(uu)::value;
+        constexpr int RS = RSL0 < 0 ? -1 : (RSL0 + UU * KIN) % RING_STEPS;
+        constexpr int T0 = (UU * KIN) % PAGE_STEPS;
+        constexpr bool LAST = (UU == NT - 1) && (KIN == KS);
+        f32x16 acc = bias_tile(bias + 32 * UU, h);
+        if constexpr (UU == 0)
+          acc = tile<KIN, T0, HAS_CARRY, RS, STASH, false, false>(ring, p, acc, xhi, xlo, prev, xhi[XL], xlo[XL], xhi[XL + 1],
+                                                                  xlo[XL + 1], st, st_prev + XL * 1024, CD, scratch);
+        else
+          acc = tile<KIN, T0, true, RS, STASH, true, LAST>(ring, p, acc, xhi, xlo, prev, th0, tl0, th1, tl1, st,
+                                                           st_own + (2 * UU - 2) * 1024, CD, scratch, (2 * UU - 2) * 2048);
+        prev = acc;
+      });
+      return prev;
+    }
 #pragma unroll
     for (int U = 0; U < NT; ++U) {
       f32x16 acc = bias_tile(bias + 32 * U, h);
@@ -344,19 +392,10 @@ struct Mlp {
       if (U == UU) {                                                                                               \
         constexpr int RS = RSL0 < 0 ? -1 : (RSL0 + UU * KIN) % RING_STEPS;                                         \
         constexpr int T0 = (UU * KIN) % PAGE_STEPS;                                                               \
-        if constexpr (!SPILL) {                                                                                    \
-          if (UU == 0) acc = tile<KIN, T0, HAS_CARRY, RS, STASH>(ring, p, acc, xhi, xlo, prev, xhi[XL], xlo[XL], xhi[XL + 1], xlo[XL + 1], st_prev + XL * 1024, CD); \
-          else acc = tile<KIN, T0, true, RS, STASH>(ring, p, acc, xhi, xlo, prev, yhi[2 * UU - 2], ylo[2 * UU - 2], yhi[2 * UU - 1], ylo[2 * UU - 1], st_own + (2 * UU - 2) * 1024, CD); \
-        } else {                                                                                                   \
-          constexpr bool LAST = (UU == NT - 1) && (KIN == KS);                                                     \
-          if (UU == 0) acc = tile<KIN, T0, HAS_CARRY, RS, STASH, false, false>(ring, p, acc, xhi, xlo, prev, xhi[XL], xlo[XL], xhi[XL + 1], xlo[XL + 1], st_prev + XL * 1024, CD); \
-          else acc = tile<KIN, T0, true, RS, STASH, true, LAST>(ring, p, acc, xhi, xlo, prev, th0, tl0, th1, tl1, st_own + (2 * UU - 2) * 1024, CD, scratch + (2 * UU - 2) * 2048, scratch); \
-        }                                                                                                          \
+        if (UU == 0) acc = tile<KIN, T0, HAS_CARRY, RS, STASH>(ring, p, acc, xhi, xlo, prev, xhi[XL], xlo[XL], xhi[XL + 1], xlo[XL + 1], st, st_prev + XL * 1024, CD, scratch); \
+        else acc = tile<KIN, T0, true, RS, STASH>(ring, p, acc, xhi, xlo, prev, yhi[2 * UU - 2], ylo[2 * UU - 2], yhi[2 * UU - 1], ylo[2 * UU - 1], st, st_own + (2 * UU - 2) * 1024, CD, scratch); \
       }
       SUNERF_TILE(0) SUNERF_TILE(1) SUNERF_TILE(2) SUNERF_TILE(3) SUNERF_TILE(4) SUNERF_TILE(5) SUNERF_TILE(6) SUNERF_TILE(7)
-      if constexpr (NT > 8) {
-        SUNERF_TILE(8) SUNERF_TILE(9) SUNERF_TILE(10) SUNERF_TILE(11) SUNERF_TILE(12) SUNERF_TILE(13) SUNERF_TILE(14) SUNERF_TILE(15)
-      }
 #undef SUNERF_TILE
       prev = acc;
     }
@@ -365,10 +404,10 @@ struct Mlp {
 
   template <bool STASH>
   static __device__ __forceinline__ f32x16 out_layer(Ring<D>& ring, Pipe& p, const float* bias, int h, half8* xhi,
-                                                     half8* xlo, const f32x16& carry, char* st_prev) {
+                                                     half8* xlo, const f32x16& carry, Rsrc st, int st_prev, Rsrc scratch) {
     constexpr int XL = 2 * NT - 2;
     return tile<KS, 0, true, RS_HIDDEN, STASH, false, false>(ring, p, bias_tile(bias, h), xhi, xlo, carry, xhi[XL], xlo[XL],
-                                                             xhi[XL + 1], xlo[XL + 1], st_prev + XL * 1024, KS * 1024);
+                                                             xhi[XL + 1], xlo[XL + 1], st, st_prev + XL * 1024, KS * 1024, scratch);
   }
 };
 
@@ -381,7 +420,7 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
   char* slot = smem;                                            // ring of NSLOT weight pages
   float* bias = (float*)(smem + (size_t)Ring<D>::RING);          // n_bias floats
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 31, h = lane >> 5;
 
   {  // biases -> LDS once
@@ -421,11 +460,11 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
       const float v[4] = {px, py, pz, tm};
 
       // training: this chunk's slice of the activation stash (lane-adjusted); enc fragments first
-      char* sbase = nullptr;
+      Rsrc st = make_rsrc(nullptr, 0);
       if (STASH) {
         // waves of a ragged last group (no ray) run the same instruction stream: they write to one spare chunk
         const size_t chunk_id = ray_ok ? (size_t)ray_raw * n_chunks + c : (size_t)a.n_rays * n_chunks;
-        sbase = a.stash + chunk_id * SL.chunk_bytes() + lane * 16;
+        st = make_rsrc(a.stash + chunk_id * SL.chunk_bytes(), (unsigned)SL.chunk_bytes());   // wave-uniform base
       }
       f32x16 out;
       const float* obias = bias + (size_t)(a.n_linear - 1) * D;
@@ -442,31 +481,32 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
         }
         if (STASH) {
 #pragma unroll
-          for (int s = 0; s < SUNERF_KS0; ++s) *(half8*)(sbase + s * 1024) = xb_hi[s];
+          for (int s = 0; s < SUNERF_KS0; ++s) buf_store(xb_hi[s], st, s * 1024);
         }
         // in layer: 84(96) -> D
         f32x16 carry = {0};
+        const Rsrc none = make_rsrc(nullptr, 0);
         carry = M::template layer<SUNERF_KS0, false, M::RS_IN, STASH>(ring, pipe, bias, h, xb_hi, xb_lo, xa_hi, xa_lo, carry,
-                                                                      nullptr, sbase + SL.h_off(0));
+                                                                      st, 0, (int)SL.h_off(0), none);
         // hidden layers, ping-pong between the two register sets
         int l = 1;
         for (; l + 1 < a.n_linear - 1; l += 2) {
           carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)l * D, h, xa_hi, xa_lo, xb_hi, xb_lo,
-                                                                      carry, sbase + SL.h_off(l - 1), sbase + SL.h_off(l));
+                                                                      carry, st, (int)SL.h_off(l - 1), (int)SL.h_off(l), none);
           carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)(l + 1) * D, h, xb_hi, xb_lo, xa_hi,
-                                                                      xa_lo, carry, sbase + SL.h_off(l), sbase + SL.h_off(l + 1));
+                                                                      xa_lo, carry, st, (int)SL.h_off(l), (int)SL.h_off(l + 1), none);
         }
         if (l < a.n_linear - 1) {
           carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)l * D, h, xa_hi, xa_lo, xb_hi, xb_lo,
-                                                                      carry, sbase + SL.h_off(l - 1), sbase + SL.h_off(l));
-          out = M::template out_layer<STASH>(ring, pipe, obias, h, xb_hi, xb_lo, carry, sbase + SL.h_off(l));
+                                                                      carry, st, (int)SL.h_off(l - 1), (int)SL.h_off(l), none);
+          out = M::template out_layer<STASH>(ring, pipe, obias, h, xb_hi, xb_lo, carry, st, (int)SL.h_off(l), none);
         } else {
-          out = M::template out_layer<STASH>(ring, pipe, obias, h, xa_hi, xa_lo, carry, sbase + SL.h_off(l - 1));
+          out = M::template out_layer<STASH>(ring, pipe, obias, h, xa_hi, xa_lo, carry, st, (int)SL.h_off(l - 1), none);
         }
       } else {
         // d_filter = 512: ONE activation set in registers (256 AGPRs); every layer writes its output fragments to this
         // wave's scratch and the last tile of the layer pulls them back in as the next layer's input
-        char* scratch = a.scratch + ((size_t)blockIdx.x * WAVES + wave) * ((size_t)M::KS * 2048) + lane * 16;
+        const Rsrc scratch = make_rsrc(a.scratch + ((size_t)blockIdx.x * WAVES + wave) * ((size_t)M::KS * 2048), M::KS * 2048);
         half8 x_hi[M::KS], x_lo[M::KS];
         encode_point(v, h, [&](int q, float val) {
           const _Float16 hi = (_Float16)val;
@@ -477,23 +517,29 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
         for (int s = 0; s < SUNERF_KS0; ++s) { pin_agpr(x_hi[s]); pin_agpr(x_lo[s]); }
         if (STASH) {
 #pragma unroll
-          for (int s = 0; s < SUNERF_KS0; ++s) *(half8*)(sbase + s * 1024) = x_hi[s];
+          for (int s = 0; s < SUNERF_KS0; ++s) buf_store(x_hi[s], st, s * 1024);
         }
         f32x16 carry = {0};
         carry = M::template layer<SUNERF_KS0, false, M::RS_IN, STASH>(ring, pipe, bias, h, x_hi, x_lo, nullptr, nullptr, carry,
-                                                                      nullptr, sbase + SL.h_off(0), scratch);
+                                                                      st, 0, (int)SL.h_off(0), scratch);
         // the in layer's tiles are too short to pull the next input in one by one: fetch fragments 0 .. KS-3 now (the
         // last two arrive through the carry epilogue)
+        // (in groups of 4 k-steps: all 60 loads in flight at once would need 240 transit VGPRs on their way to the AGPRs)
 #pragma unroll
-        for (int s = 0; s < M::KS - 2; ++s) {
-          x_hi[s] = *(const half8*)(scratch + s * 2048);
-          x_lo[s] = *(const half8*)(scratch + s * 2048 + 1024);
-          pin_agpr(x_hi[s]); pin_agpr(x_lo[s]);
+        for (int s0 = 0; s0 < M::KS - 2; s0 += 4) {
+#pragma unroll
+          for (int s = s0; s < s0 + 4 && s < M::KS - 2; ++s) {
+            x_hi[s] = buf_load(scratch, s * 2048);
+            x_lo[s] = buf_load(scratch, s * 2048 + 1024);
+          }
+#pragma unroll
+          for (int s = s0; s < s0 + 4 && s < M::KS - 2; ++s) { pin_agpr(x_hi[s]); pin_agpr(x_lo[s]); }
+          __builtin_amdgcn_sched_barrier(0);
         }
         for (int l = 1; l < a.n_linear - 1; ++l)
           carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)l * D, h, x_hi, x_lo, nullptr, nullptr,
-                                                                      carry, sbase + SL.h_off(l - 1), sbase + SL.h_off(l), scratch);
-        out = M::template out_layer<STASH>(ring, pipe, obias, h, x_hi, x_lo, carry, sbase + SL.h_off(a.n_linear - 2));
+                                                                      carry, st, (int)SL.h_off(l - 1), (int)SL.h_off(l), scratch);
+        out = M::template out_layer<STASH>(ring, pipe, obias, h, x_hi, x_lo, carry, st, (int)SL.h_off(a.n_linear - 2), scratch);
       }
 
       // ---- emission / absorption integral for this chunk (emission.py:14-54); lanes 0..31 hold rows 0,1 ----

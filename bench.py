@@ -90,17 +90,31 @@ def cpu_baseline(res, samples, mode, seconds_budget=20.0):
 
 
 
-def two_pass_rate(dev, world, rays_o, rays_d, times, target, batch, samples, steps=3, warmup=1):
+def two_pass_rate(dev, world, rays_o, rays_d, times, target, batch, samples, steps=3, warmup=1, density_temperature=False):
     """Reference-shaped training step beside the single-pass headline: StratifiedSampler (S/2 jittered
     samples) -> coarse pass -> HierarchicalSampler (S/2 more) -> fine pass over S samples -> loss on both images ->
     backward through both models -> all-reduce + clip + Adam.  MLP evaluations per ray: S/2 + S."""
     from sunerf.rendering.emission import EmissionRadiativeTransfer
     from sunerf_hip.train import ClipAdam, training_loss
     torch.manual_seed(7)
-    rendering = EmissionRadiativeTransfer(
-        Rs_per_ds=1.0, sampling_config={'type': 'stratified', 'n_samples': samples // 2},
-        hierarchical_sampling_config={'type': 'hierarchical', 'n_samples': samples // 2},
-        model_config={'d_filter': D_FILTER, 'n_layers': N_LAYERS}).to(dev)
+    cfg = dict(Rs_per_ds=1.0, sampling_config={'type': 'stratified', 'n_samples': samples // 2},
+               hierarchical_sampling_config={'type': 'hierarchical', 'n_samples': samples // 2},
+               model_config={'d_filter': D_FILTER, 'n_layers': N_LAYERS})
+    wavelengths = None
+    if density_temperature:
+        # BASELINE config 5: NeRF_DT dual head, 7 AIA channels on every ray (run_density_temperature.py path).  The AIA
+        # response is a synthetic log-normal bump per channel (the .genx table is data, not part of the timed work).
+        import numpy as np
+        from sunerf.model.model import NeRF_DT
+        from sunerf.rendering.density_temperature import DensityTemperatureRadiativeTransfer
+        logte = np.tile(np.linspace(4.0, 9.0, 101, dtype=np.float32), (7, 1))
+        peaks = np.array([6.8, 5.6, 5.9, 6.2, 6.3, 4.9, 5.4], dtype=np.float64)[:, None]
+        tresp = 1e-25 * np.exp(-0.5 * ((logte - peaks) / 0.15) ** 2)
+        rendering = DensityTemperatureRadiativeTransfer(model=NeRF_DT, response_table=(logte, tresp), **cfg).to(dev)
+        wavelengths = torch.tensor([[94., 131., 171., 193., 211., 304., 335.]], device=dev).repeat(batch, 1)
+        target = torch.rand(target.shape[0], 7, generator=torch.Generator().manual_seed(1)).to(dev)
+    else:
+        rendering = EmissionRadiativeTransfer(**cfg).to(dev)
     opt = ClipAdam(rendering.parameters(), lr=1e-4, max_norm=0.5)
     n_batches = max(1, rays_o.shape[0] // batch)
 
@@ -108,9 +122,12 @@ def two_pass_rate(dev, world, rays_o, rays_d, times, target, batch, samples, ste
         b = (i % n_batches) * batch
         sl = slice(b, b + batch)
         opt.zero_grad()
-        out = rendering(rays_o[sl], rays_d[sl], times[sl].reshape(-1, 1))
+        if density_temperature:
+            out = rendering(rays_o[sl], rays_d[sl], times[sl].reshape(-1, 1), wavelengths)
+        else:
+            out = rendering(rays_o[sl], rays_d[sl], times[sl].reshape(-1, 1))
         loss, stats = training_loss(out['coarse_image'], out['fine_image'], target[sl], out['regularization'], 1.0, 1.0,
-                                    asinh_scaling=(1.0, 0.005),
+                                    asinh_scaling=None if density_temperature else (1.0, 0.005),
                                     finite_check=[out['height_map'], out['absorption_map'], out['z_vals_stratified'],
                                                   out['z_vals_hierarchical']])
         loss.backward()
@@ -135,7 +152,8 @@ def two_pass_rate(dev, world, rays_o, rays_d, times, target, batch, samples, ste
     evals = samples // 2 + samples
     return {'value': batch * evals * world * steps / el.item(), 'unit': 'ray-samples/s',
             'mlp_evaluations_per_ray': evals, 'ms_per_step': el.item() / steps * 1e3, 'steps': steps,
-            'what': f'coarse pass {samples // 2} + hierarchical resampling + fine pass {samples} samples per ray, two models, '
+            'what': ('density-temperature head (7 channels): ' if density_temperature else '')
+                    + f'coarse pass {samples // 2} + hierarchical resampling + fine pass {samples} samples per ray, two models, '
                     'loss + backward + all-reduce + clip + Adam'}
 
 
@@ -150,6 +168,8 @@ def main():
     ap.add_argument('--mode', choices=['train', 'fwd'], default='train')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-two-pass', action='store_true', help='skip the reference-shaped two-pass figure (train mode)')
+    ap.add_argument('--dt', action='store_true', help='also time BASELINE config 5: density-temperature head, two-pass, '
+                                                      '256 samples per ray in the fine pass (reported under "dt_two_pass")')
     ap.add_argument('--d-filter', type=int, default=D_FILTER, help='MLP width (headline: 256; 512 = reference default, fwd only)')
     args = ap.parse_args()
     globals()['D_FILTER'] = args.d_filter
@@ -245,11 +265,14 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
-    two_pass = None
+    two_pass = dt_two_pass = None
     if args.mode == 'train' and not args.no_two_pass:      # after the timed region of the headline metric
         del opt, model
         torch.cuda.empty_cache()
         two_pass = two_pass_rate(dev, world, rays_o, rays_d, times, target, B, args.samples)
+        if args.dt:
+            torch.cuda.empty_cache()
+            dt_two_pass = two_pass_rate(dev, world, rays_o, rays_d, times, target, min(B, 8192), 256, density_temperature=True)
     samples_per_step = rays_per_step * args.samples * world
     value = samples_per_step * args.steps / elapsed
 
@@ -259,7 +282,11 @@ def main():
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get(f'{args.mode}_bytes_per_step')
+                t = json.load(f)
+            measured_on = t.get(f'{args.mode}_config', {})
+            here = {'rays': rays_per_step, 'samples': args.samples, 'd_filter': D_FILTER}
+            if all(measured_on.get(k) == v for k, v in here.items()):
+                traffic = t.get(f'{args.mode}_bytes_per_step')
         what = 'fwd+bwd' if args.mode == 'train' else 'fwd'
         line = {
             'metric': f'ray-samples/sec ({what}, fused emission renderer)', 'value': value, 'unit': 'ray-samples/s',
@@ -280,6 +307,8 @@ def main():
         }
         if two_pass is not None:
             line['two_pass'] = two_pass
+        if dt_two_pass is not None:
+            line['dt_two_pass'] = dt_two_pass
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.res, args.samples, args.mode)
         print(json.dumps(line), flush=True)

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Kernel-trace stats + HBM traffic counters of the two bench modes (run on the GPU box through gpurun).
+# PMC passes are separate runs without any trace domain (gpurun refuses --pmc combined with traces).
+set -e
+R=/root/repo
+OUT=$R/gpurun_out/prof_round
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+for mode in train fwd; do
+  extra="--no-cpu-baseline --no-two-pass --steps 3 --warmup 1 --mode $mode"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${mode}_stats -- python3 $R/bench.py $extra > $OUT/${mode}_stats.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${mode}_fetch -- python3 $R/bench.py $extra > $OUT/${mode}_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${mode}_write -- python3 $R/bench.py $extra > $OUT/${mode}_write.log 2>&1
+  echo "$mode done"
+done
