@@ -234,7 +234,17 @@ template <int D>
 __global__ __launch_bounds__(WG_THREADS, 1) void wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // NBUF chunk buffers + 1 KiB dummy target + slack
   constexpr int NQ = wg_quads(D);
-  const int q = blockIdx.x % (NQ * NQ), ls = blockIdx.x / (NQ * NQ);
+  int q, ls;
+  if (NQ == 1) {
+    q = 0; ls = blockIdx.x;
+  } else {
+    // the 2 x 2 workgroups of one (layer, slice) read the same dZ / H halves pairwise: put them on the SAME XCD (workgroup
+    // i runs on XCD i % 8) so that the second reader of a chunk hits that XCD's L2 instead of going to HBM again
+    const int xcd = blockIdx.x & 7, g = blockIdx.x >> 5;
+    q = (blockIdx.x >> 3) & 3;
+    ls = g * 8 + xcd;
+    if (ls >= a.n_linear * a.split) return;
+  }
   const int layer = ls / a.split, split = ls % a.split;
   const int qa = q / NQ, qb = q % NQ;
   if (layer == 0) wgrad_body<D, 0>(a, smem, layer, split, qa, qb);
@@ -345,7 +355,8 @@ extern "C" int sunerf_mlp_wgrad(int d_filter, int n_linear, int d_out, const voi
   // every (layer, split) slot of the workspace that the reduce kernel reads is written by exactly one workgroup; slots of
   // workgroups without chunks hold zeros from their zero-initialised accumulators
   SUNERF_CLEAR_ERROR();
-  const unsigned grid = (unsigned)(n_linear * split * nq * nq);
+  // d = 512: groups of 8 (layer, slice) pairs x 4 blocks, see wgrad_kernel
+  const unsigned grid = nq == 1 ? (unsigned)(n_linear * split) : (unsigned)((n_linear * split + 7) / 8 * 32);
   switch (d_filter) {
     case 64: hipLaunchKernelGGL(wgrad_kernel<64>, dim3(grid), dim3(WG_THREADS), lds, st, a); break;
     case 128: hipLaunchKernelGGL(wgrad_kernel<128>, dim3(grid), dim3(WG_THREADS), lds, st, a); break;
