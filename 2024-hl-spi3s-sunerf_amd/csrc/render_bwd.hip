@@ -19,67 +19,98 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------
-// integral backward: one thread per ray, sequential over the samples (O(S) flops, HBM-light)
+// integral backward: 32 lanes per ray, one sample per lane and 32-sample chunk (coalesced reads of raw / z and writes of
+// g_raw; the two sweeps along the ray are chunk-wise scans with a scalar carry, like the forward kernel's integral)
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int IB_THREADS = 64;
+constexpr int IB_THREADS = 256;                // 8 rays per workgroup
+constexpr int IB_RAYS = IB_THREADS / 32;
 
 __global__ __launch_bounds__(IB_THREADS) void integral_bwd_kernel(
     const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ g_image, const float* __restrict__ g_reg,
     float g_reg_const, float reg_radius, int64_t n_rays, int S, float* __restrict__ g_raw,
     unsigned* __restrict__ g_absmax_bits) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // [S][IB_THREADS] emerging intensity I*T
-  const int tid = threadIdx.x;
-  const int64_t ray = (int64_t)blockIdx.x * IB_THREADS + tid;
-  float local_max = 0.f;
-  if (ray < n_rays) {
-    const float ox = rays_o[ray * 3 + 0], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
-    const float dx = rays_d[ray * 3 + 0], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
-    const float dnorm = sqrtf((dx * dx + dy * dy) + dz * dz);
-    const float* z = z_vals + ray * S;
-    const float* r = raw + ray * S * 2;
-    float* g = g_raw + ray * S * 2;
-    const float gi = g_image[ray];
-    // forward recomputation: emerging_i = I_i * T_i, T the exclusive product of (a + 1e-10)
-    float T = 1.f;
-    for (int i = 0; i < S; ++i) {
-      const float dzv = (i == 0) ? (z[1] - z[0]) : (z[i] - z[i - 1]);
-      const float dist = dzv * dnorm;
-      const float a = expf(-fmaxf(r[2 * i + 1], 0.f) * dist);
-      lds[i * IB_THREADS + tid] = expf(r[2 * i]) * dist * T;
-      T *= a + 1e-10f;
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [IB_RAYS][3][Sp]: emerging intensity, a, dist
+  const int tid = threadIdx.x, n = tid & 31, sub = tid >> 5;
+  const int64_t ray_raw = (int64_t)blockIdx.x * IB_RAYS + sub;
+  const bool ray_ok = ray_raw < n_rays;
+  const int64_t ray = ray_ok ? ray_raw : n_rays - 1;
+  const int n_chunks = (S + 31) >> 5, Sp = n_chunks * 32;
+  float* em_s = lds + (size_t)sub * 3 * Sp;
+  float* a_s = em_s + Sp;
+  float* dist_s = a_s + Sp;
+  const float ox = rays_o[ray * 3 + 0], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
+  const float dx = rays_d[ray * 3 + 0], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+  const float dnorm = sqrtf((dx * dx + dy * dy) + dz * dz);
+  const float* z = z_vals + ray * S;
+  const float* r = raw + ray * S * 2;
+  const float gi = g_image[ray];
+  // ---- sweep 1 (along the ray): emerging_i = I_i * T_i, T the exclusive product of (a + 1e-10) ----
+  float carry_T = 1.f, carry_z = 0.f;
+  const float z0 = z[0], z1 = z[1];
+  for (int c = 0; c < n_chunks; ++c) {
+    const int i = 32 * c + n;
+    const bool valid = i < S;
+    const float zi = z[valid ? i : S - 1];
+    float zprev = __shfl_up(zi, 1, 32);
+    if (n == 0) zprev = carry_z;
+    const float dzv = (i == 0) ? (z1 - z0) : (zi - zprev);
+    const float dist = dzv * dnorm;
+    const f32x2 rr = *(const f32x2*)(r + 2 * (valid ? i : S - 1));
+    const float a = expf(-fmaxf(rr[1], 0.f) * dist);
+    float pr = valid ? (a + 1e-10f) : 1.f;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+      const float o = __shfl_up(pr, d, 32);
+      if (n >= d) pr *= o;
     }
-    // reverse sweep: suffix_i = sum_{k>i} emerging_k
-    float suffix = 0.f;
-    for (int i = S - 1; i >= 0; --i) {
-      const float zi = z[i];
-      const float dzv = (i == 0) ? (z[1] - z[0]) : (zi - z[i - 1]);
-      const float dist = dzv * dnorm;
+    float excl = __shfl_up(pr, 1, 32);
+    if (n == 0) excl = 1.f;
+    em_s[i] = valid ? expf(rr[0]) * dist * (carry_T * excl) : 0.f;
+    a_s[i] = a;
+    dist_s[i] = dist;
+    carry_T *= __shfl(pr, 31, 32);
+    carry_z = __shfl(zi, 31, 32);
+  }
+  // ---- sweep 2 (against the ray): suffix_i = sum_{k > i} emerging_k ----
+  float local_max = 0.f, carry_suffix = 0.f;
+  for (int c = n_chunks - 1; c >= 0; --c) {
+    const int i = 32 * c + n;
+    const bool valid = i < S;
+    const float em = em_s[i];
+    float incl = em;                                   // inclusive suffix sum within the chunk
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+      const float o = __shfl_down(incl, d, 32);
+      if (n + d < 32) incl += o;
+    }
+    const float suffix = carry_suffix + (incl - em);
+    carry_suffix += __shfl(incl, 0, 32);
+    if (valid && ray_ok) {
+      const float a = a_s[i], dist = dist_s[i];
       const float r1 = r[2 * i + 1];
-      const float a = expf(-fmaxf(r1, 0.f) * dist);
-      const float em = lds[i * IB_THREADS + tid];
       // image = sum_i em_i :  d/d r0_i = em_i ;  d/d a_i = suffix_i / (a_i + 1e-10)
       const float g0 = gi * em;
       float ga = gi * suffix / (a + 1e-10f);
       // regularization_i = relu(|p_i| - R) (1 - a_i)   (base_tracing.py:43-44, D2 resolved)
       const float gr = g_reg ? g_reg[ray * S + i] : g_reg_const;
       if (gr != 0.f) {
+        const float zi = z[i];
         const float px = ox + dx * zi, py = oy + dy * zi, pz = oz + dz * zi;
         const float pd = sqrtf((px * px + py * py) + pz * pz);
         ga -= gr * fmaxf(pd - reg_radius, 0.f);
       }
       // a = exp(-relu(r1) dist)
       const float g1 = (r1 > 0.f) ? ga * (-dist * a) : 0.f;
-      g[2 * i] = g0;
-      g[2 * i + 1] = g1;
+      const f32x2 gg = {g0, g1};
+      *(f32x2*)(g_raw + ((size_t)ray * S + i) * 2) = gg;
       local_max = fmaxf(local_max, fmaxf(fabsf(g0), fabsf(g1)));
-      suffix += em;
     }
   }
   // max |g_raw| of the batch (bit pattern of a non-negative float orders like an unsigned integer)
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, d));
-  if (tid == 0 && local_max > 0.f && local_max < INFINITY) atomicMax(g_absmax_bits, __float_as_uint(local_max));
+  if ((tid & 63) == 0 && local_max > 0.f && local_max < INFINITY) atomicMax(g_absmax_bits, __float_as_uint(local_max));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -638,7 +669,7 @@ extern "C" int sunerf_emission_integral_bwd(const float* raw, const float* z_val
                                             int64_t n_rays, int n_samples, float* g_raw, void* g_absmax, void* stream) {
   if (n_rays < 0 || n_samples < 2 || !g_absmax) return SUNERF_E_BADARG;
   if (n_rays > 0 && (!raw || !z_vals || !rays_o || !rays_d || !g_image || !g_raw)) return SUNERF_E_BADARG;
-  const size_t lds = (size_t)n_samples * IB_THREADS * sizeof(float);
+  const size_t lds = (size_t)IB_RAYS * 3 * (size_t)((n_samples + 31) / 32 * 32) * sizeof(float);
   if (lds > 160 * 1024) return SUNERF_E_UNSUPPORTED;
   hipError_t e = hipMemsetAsync(g_absmax, 0, 4, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
@@ -647,7 +678,7 @@ extern "C" int sunerf_emission_integral_bwd(const float* raw, const float* z_val
     e = hipFuncSetAttribute((const void*)integral_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  const int64_t blocks = (n_rays + IB_THREADS - 1) / IB_THREADS;
+  const int64_t blocks = (n_rays + IB_RAYS - 1) / IB_RAYS;
   SUNERF_CLEAR_ERROR();
   hipLaunchKernelGGL(integral_bwd_kernel, dim3((unsigned)blocks), dim3(IB_THREADS), lds, (hipStream_t)stream, raw, z_vals,
                      rays_o, rays_d, g_image, g_reg, g_reg_const, reg_radius, n_rays, n_samples, g_raw, (unsigned*)g_absmax);

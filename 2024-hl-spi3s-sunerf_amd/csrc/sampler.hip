@@ -53,77 +53,106 @@ __global__ void sample_z_kernel(int kind, const float* __restrict__ rays_o, cons
 // lookup is discontinuous in the CDF values, so it is kept sequential rather than re-associated by a parallel
 // scan.  Per-thread scratch (cdf, bins) lives in LDS, laid out [element][thread] (conflict-free).
 // Work per ray is O(S_c + S_f); the kernel moves (2*S_c + 2*S_f + S_c) * 4 bytes per ray.
-constexpr int RS_THREADS = 64;
+constexpr int RS_THREADS = 256;
+constexpr int RS_G = 8;                         // lanes per ray
+constexpr int RS_RAYS = RS_THREADS / RS_G;      // rays per workgroup
 
+// 8 lanes per ray.  The CDF (a 62-step fp64 running sum whose rounding decides which side of the reference's thresholds a
+// sample falls on) is built by the group's first lane exactly as a single thread would; the S_f inverse-CDF searches and
+// the merge -- as rank computations: position of z_i = i + #{new < z_i}, position of new_j = j + #{z <= new_j}, the order a
+// stable two-run merge produces -- are dealt out over the 8 lanes.  Lanes of a group sit in one wave, LDS operations of a
+// wave complete in order, so no barrier separates the phases.
 __global__ __launch_bounds__(RS_THREADS) void hier_resample_kernel(
     const float* __restrict__ z_vals, const float* __restrict__ weights, const float* __restrict__ u_in,
     int u_per_ray, int64_t n_rays, int Sc, int Sf, float* __restrict__ new_z_out, float* __restrict__ z_comb) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x;
-  const int64_t ray = (int64_t)blockIdx.x * RS_THREADS + tid;
-  if (ray >= n_rays) return;
+  const int tid = threadIdx.x, g = tid & (RS_G - 1), sub = tid / RS_G;
+  const int64_t ray_raw = (int64_t)blockIdx.x * RS_RAYS + sub;
+  const bool ray_ok = ray_raw < n_rays;
+  const int64_t ray = ray_ok ? ray_raw : n_rays - 1;      // surplus groups shadow the last ray (no stores)
   const int nb = Sc - 1;                 // number of bins (mid points) == cdf entries
-  float* cdf = lds;                      // [nb][RS_THREADS]
-  float* bins = lds + (size_t)nb * RS_THREADS;
-  float* nz = bins + (size_t)nb * RS_THREADS;   // [Sf][RS_THREADS] new samples (for the merge)
+  float* cdf = lds + (size_t)sub * (2 * nb + Sf + Sc);    // [nb]
+  float* bins = cdf + nb;                // [nb]
+  float* nz = bins + nb;                 // [Sf] new samples
+  float* zc = nz + Sf;                   // [Sc] coarse samples
   const float* z = z_vals + ray * Sc;
   const float* w = weights + ray * Sc;
-  // pdf = (w[1:-1] + 1e-5) / sum(w[1:-1] + 1e-5)      (Sc-2 entries)
-  // torch's CPU cumsum accumulates fp32 inputs in fp64 and rounds every output to fp32; its sum is a cascaded
-  // (more-accurate-than-sequential) fp32 sum.  fp64 accumulators reproduce the former exactly and the latter to
-  // the last bit in almost all cases (62 fp64 adds per ray: free on this HBM-bound kernel).
-  double wsum_d = 0.0;
-  for (int i = 1; i < Sc - 1; ++i) wsum_d += (double)(w[i] + 1e-5f);
-  const float wsum = (float)wsum_d;
-  double run = 0.0;
-  cdf[0 * RS_THREADS + tid] = 0.f;
-  for (int i = 1; i < Sc - 1; ++i) {
-    run += (double)((w[i] + 1e-5f) / wsum);
-    cdf[i * RS_THREADS + tid] = (float)run;
-  }
-  float zprev = z[0];
+  for (int i = g; i < Sc; i += RS_G) zc[i] = z[i];
   bool z_sorted = true;
-  for (int i = 0; i < nb; ++i) {
-    const float zn = z[i + 1];
-    bins[i * RS_THREADS + tid] = .5f * (zn + zprev);
-    z_sorted = z_sorted && (zn >= zprev);
-    zprev = zn;
+  if (g == 0) {
+    // pdf = (w[1:-1] + 1e-5) / sum(w[1:-1] + 1e-5)      (Sc-2 entries)
+    // torch's CPU cumsum accumulates fp32 inputs in fp64 and rounds every output to fp32; its sum is a cascaded
+    // (more-accurate-than-sequential) fp32 sum.  fp64 accumulators reproduce the former exactly and the latter to
+    // the last bit in almost all cases.
+    double wsum_d = 0.0;
+    for (int i = 1; i < Sc - 1; ++i) wsum_d += (double)(w[i] + 1e-5f);
+    const float wsum = (float)wsum_d;
+    double run = 0.0;
+    cdf[0] = 0.f;
+    for (int i = 1; i < Sc - 1; ++i) {
+      run += (double)((w[i] + 1e-5f) / wsum);
+      cdf[i] = (float)run;
+    }
   }
-  // inverse CDF
-  bool sorted = true;
-  float last = -INFINITY;
-  for (int j = 0; j < Sf; ++j) {
+  for (int i = g; i < nb; i += RS_G) {
+    const float z0 = z[i], z1 = z[i + 1];
+    bins[i] = .5f * (z1 + z0);
+    z_sorted = z_sorted && (z1 >= z0);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // inverse CDF: sample j of this lane
+  for (int j = g; j < Sf; j += RS_G) {
     const float u = u_per_ray ? u_in[ray * Sf + j] : u_in[j];
     // searchsorted(cdf, u, right=True): first index with cdf[idx] > u   (binary search, nb entries)
     int lo = 0, hi = nb;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      if (cdf[mid * RS_THREADS + tid] > u) hi = mid; else lo = mid + 1;
+      if (cdf[mid] > u) hi = mid; else lo = mid + 1;
     }
     const int below = max(lo - 1, 0), above = min(lo, nb - 1);
-    const float c0 = cdf[below * RS_THREADS + tid], c1 = cdf[above * RS_THREADS + tid];
-    const float b0 = bins[below * RS_THREADS + tid], b1 = bins[above * RS_THREADS + tid];
+    const float c0 = cdf[below], c1 = cdf[above];
+    const float b0 = bins[below], b1 = bins[above];
     float denom = c1 - c0;
     if (denom < 1e-5f) denom = 1.f;
     const float t = (u - c0) / denom;
-    const float s = b0 + t * (b1 - b0);
-    new_z_out[ray * Sf + j] = s;
-    nz[j * RS_THREADS + tid] = s;
-    sorted = sorted && (s >= last);
-    last = s;
+    const float sv = b0 + t * (b1 - b0);
+    if (ray_ok) new_z_out[ray * Sf + j] = sv;
+    nz[j] = sv;
   }
+  __builtin_amdgcn_wave_barrier();
+  bool sorted = z_sorted;
+  for (int j = g; j < Sf; j += RS_G)
+    if (j > 0) sorted = sorted && (nz[j] >= nz[j - 1]);
+  // both runs ascending?  (and-reduce over the group's 8 lanes)
+  int ok = sorted ? 1 : 0;
+  ok &= __shfl_xor(ok, 1);
+  ok &= __shfl_xor(ok, 2);
+  ok &= __shfl_xor(ok, 4);
+  if (!ray_ok) return;
   // z_vals_combined = sort(cat[z_vals, new_z])  (sampling.py:122)
   float* out = z_comb + ray * (Sc + Sf);
-  if (sorted && z_sorted) {  // the normal case: merge of two ascending runs
-    int i = 0, j = 0;
-    for (int k = 0; k < Sc + Sf; ++k) {
-      const float a = (i < Sc) ? z[i] : INFINITY;
-      const float b = (j < Sf) ? nz[j * RS_THREADS + tid] : INFINITY;
-      if (j >= Sf || (i < Sc && a <= b)) { out[k] = a; ++i; } else { out[k] = b; ++j; }
+  if (ok) {  // the normal case: merge of two ascending runs, by rank
+    for (int i = g; i < Sc; i += RS_G) {
+      const float v = zc[i];
+      int lo = 0, hi = Sf;                       // #{new < v}
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (nz[mid] < v) lo = mid + 1; else hi = mid;
+      }
+      out[i + lo] = v;
     }
-  } else {  // perturb=True (random u) or non-ascending coarse z (|d| far from 1): general insertion sort, rare path
+    for (int j = g; j < Sf; j += RS_G) {
+      const float v = nz[j];
+      int lo = 0, hi = Sc;                       // #{z <= v}
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (zc[mid] <= v) lo = mid + 1; else hi = mid;
+      }
+      out[j + lo] = v;
+    }
+  } else if (g == 0) {  // perturb=True (random u) or non-ascending coarse z (|d| far from 1): insertion sort, rare path
     for (int k = 0; k < Sc + Sf; ++k) {
-      const float v = (k < Sc) ? z[k] : nz[(k - Sc) * RS_THREADS + tid];
+      const float v = (k < Sc) ? zc[k] : nz[k - Sc];
       int m = k - 1;
       while (m >= 0 && out[m] > v) { out[m + 1] = out[m]; --m; }
       out[m + 1] = v;
@@ -157,10 +186,10 @@ extern "C" int sunerf_hier_resample(const float* z_vals, const float* weights, c
   if (n_rays < 0 || n_coarse < 3 || n_fine < 1) return SUNERF_E_BADARG;
   if (n_rays == 0) return 0;
   if (!z_vals || !weights || !u || !new_z || !z_comb) return SUNERF_E_BADARG;
-  const size_t lds = ((size_t)2 * (n_coarse - 1) + n_fine) * RS_THREADS * sizeof(float);
+  const size_t lds = ((size_t)2 * (n_coarse - 1) + n_fine + n_coarse) * RS_RAYS * sizeof(float);
   if (lds > 160 * 1024) return SUNERF_E_UNSUPPORTED;
   if (n_rays == 0) return 0;
-  const int64_t blocks = (n_rays + RS_THREADS - 1) / RS_THREADS;
+  const int64_t blocks = (n_rays + RS_RAYS - 1) / RS_RAYS;
   if (blocks > 0x7fffffffLL) return SUNERF_E_UNSUPPORTED;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)hier_resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -15,7 +15,7 @@
 namespace {
 
 constexpr int TS_THREADS = 256;
-constexpr int TS_BLOCKS = 512;
+constexpr int TS_BLOCKS = 128;
 constexpr int TS_MAX_EXTRA = 8;
 
 // workspace: [0] ticket (unsigned), then from byte 64: TS_BLOCKS x 4 doubles of block partials
@@ -259,7 +259,9 @@ extern "C" int sunerf_clip_adam_step(float* params, float* grads, float* exp_avg
   a.eps = (float)eps;
   a.step_size = (float)(lr / bc1);
   a.bias_correction2_sqrt = (float)sqrt(bc2);
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(TS_THREADS), 0, st, a);
+  // no reduction here: as many workgroups as the elements need (the reductions above are capped at TS_BLOCKS partials)
+  const int64_t adam_blocks = (n + TS_THREADS - 1) / TS_THREADS;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(adam_blocks > 4096 ? 4096 : adam_blocks)), dim3(TS_THREADS), 0, st, a);
   SUNERF_CHECK_LAUNCH();
   return 0;
 }

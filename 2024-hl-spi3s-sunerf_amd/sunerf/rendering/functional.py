@@ -18,6 +18,22 @@ def mlp_points(model, x: torch.Tensor) -> torch.Tensor:
     return out['raw'][:, 0, :]
 
 
+def _grad_targets(params):
+    """(grad_weights, grad_biases) views to accumulate into directly, or None.
+
+    When every parameter already owns a contiguous fp32 ``.grad`` on its device (``ClipAdam`` / ``GradBucket`` keep them as
+    views of one flat buffer), the weight-gradient kernel adds its result straight into it and the autograd node reports "no
+    gradient" for the parameters -- instead of returning 18 fresh tensors per model that autograd would then add to
+    ``.grad`` with 18 tiny kernels (a third of the step at the reference's default batch of 1024 rays)."""
+    grads = []
+    for p in params:
+        g = p.grad
+        if g is None or g.dtype != torch.float32 or g.device != p.device or not g.is_contiguous() or g.shape != p.shape:
+            return None
+        grads.append(g)
+    return grads[0::2], grads[1::2]
+
+
 class _EmissionPass(torch.autograd.Function):
     """One fused render pass (coarse or fine) as an autograd node.
 
@@ -28,6 +44,7 @@ class _EmissionPass(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, rays_o, rays_d, times, z_vals, reg_radius, want_epilogues, *params):
         training = any(ctx.needs_input_grad[7:])
+        ctx.set_materialize_grads(False)      # unused / non-differentiable outputs: None instead of (N,S) zero tensors
         packed = model.packed()
         out = ops.emission_render_fwd(packed, rays_o, rays_d, times, z_vals, reg_radius,
                                       want_epilogues=want_epilogues, training=training)
@@ -36,6 +53,7 @@ class _EmissionPass(torch.autograd.Function):
             ctx.packed = packed
             ctx.reg_radius = reg_radius
             ctx.n_params = len(params)
+            ctx.params = params
             ctx.param_meta = [(p.shape, p.device) for p in params]
             ctx.save_for_backward(rays_o, rays_d, z_vals, out['raw'], out['stash'])
         outs = [out['image'], out['weights'], out['absorption']]
@@ -51,9 +69,16 @@ class _EmissionPass(torch.autograd.Function):
     def backward(ctx, g_image, g_weights, g_absorption, g_hm=None, g_am=None, g_reg=None):
         rays_o, rays_d, z_vals, raw, stash = ctx.saved_tensors
         n, s = z_vals.shape
+        if g_image is None and g_reg is None:
+            return (None,) * (7 + ctx.n_params)
         if g_image is None:
             g_image = torch.zeros(n, dtype=torch.float32, device=z_vals.device)
         # parameters arrive as (W0, b0, W1, b1, ...)
+        direct = _grad_targets(ctx.params)
+        if direct is not None:
+            ops.emission_render_bwd(ctx.packed, rays_o, rays_d, z_vals, raw, stash, g_image, g_reg, 0.0, ctx.reg_radius,
+                                    direct[0], direct[1], accumulate=True)
+            return (None,) * (7 + ctx.n_params)
         gW = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[0::2]]
         gb = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[1::2]]
         ops.emission_render_bwd(ctx.packed, rays_o, rays_d, z_vals, raw, stash, g_image, g_reg, 0.0, ctx.reg_radius,
@@ -89,6 +114,7 @@ class _DtPass(torch.autograd.Function):
         n_la = len(ops.AIA_WAVELENGTHS)
         la = torch.stack([p.detach() for p in params[:n_la]])
         training = any(ctx.needs_input_grad[10:])
+        ctx.set_materialize_grads(False)
         packed = model.packed()
         mlp = ops.emission_render_fwd(packed, rays_o, rays_d, times, z_vals, 0.0, want_raw=True, training=training)
         out = ops.dt_integral_fwd(mlp['raw'], z_vals, rays_o, rays_d, wavelengths, tables[0], tables[1], la, vol_c,
@@ -98,6 +124,7 @@ class _DtPass(torch.autograd.Function):
             ctx.packed, ctx.tables, ctx.pixel_factor, ctx.reg_radius = packed, tables, pixel_factor, reg_radius
             ctx.base = (model.base_log_density, model.base_log_temperature)
             ctx.param_meta = [(p.shape, p.device) for p in params[n_la:]]
+            ctx.mlp_params = params[n_la:]
             ctx.save_for_backward(rays_o, rays_d, z_vals, wavelengths, mlp['raw'], mlp['stash'], la, vol_c.detach())
         outs = [out['image'], out['weights'], out['reg_q']]
         non_diff = [out['weights'], out['reg_q']]
@@ -115,13 +142,18 @@ class _DtPass(torch.autograd.Function):
         g_raw, g_la, g_vc, absmax = ops.dt_integral_bwd(raw, z_vals, rays_o, rays_d, wavelengths, ctx.tables[0], ctx.tables[1],
                                                         la, vol_c, ctx.base[0], ctx.base[1], ctx.pixel_factor, ctx.reg_radius,
                                                         g_image.contiguous(), g_reg)
+        head = (None,) * 10 + (g_vc.reshape(()),) + tuple(g_la[i] for i in range(g_la.shape[0]))
+        direct = _grad_targets(ctx.mlp_params)
+        if direct is not None:
+            ops.mlp_backward(ctx.packed, g_raw, absmax, stash, direct[0], direct[1], accumulate=True)
+            return head + (None,) * len(ctx.mlp_params)
         gW = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[0::2]]
         gb = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[1::2]]
         ops.mlp_backward(ctx.packed, g_raw, absmax, stash, gW, gb)
         grads = []
         for w, b in zip(gW, gb):
             grads += [w, b]
-        return (None,) * 10 + (g_vc.reshape(()),) + tuple(g_la[i] for i in range(g_la.shape[0])) + tuple(grads)
+        return head + tuple(grads)
 
 
 def dt_pass(model, tables, pixel_factor, rays_o, rays_d, times, z_vals, wavelengths, reg_radius, want_epilogues):

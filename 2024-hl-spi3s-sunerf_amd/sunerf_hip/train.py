@@ -50,6 +50,7 @@ class _TrainingLoss(torch.autograd.Function):
                                       scaling[1] if scaling else 1.0, cfg['lambda_image'], cfg['lambda_regularization'],
                                       _ptr(g_coarse), _ptr(g_fine), _ptr(stats), _ptr(ws), ws.numel(), _stream(dev))
         _l.check(st, 'sunerf_training_loss')
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(g_coarse, g_fine)
         ctx.reg_shape = None if reg is None else tuple(reg.shape)
         ctx.reg_grad = cfg['lambda_regularization'] / n_reg if n_reg else 0.0
@@ -58,6 +59,8 @@ class _TrainingLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, _g_stats):
+        if g_loss is None:
+            return None, None, None, None, None
         g_coarse, g_fine = ctx.saved_tensors
         g_reg = None
         if ctx.reg_shape is not None and ctx.needs_input_grad[3]:
