@@ -278,6 +278,11 @@ def main():
 
     if rank == 0:
         achieved = rays_per_step * args.samples * flops_per_sample / (step_ms * 1e-3) / 1e12
+        if args.mode == 'fwd':
+            executed_factor = 3.0
+        else:
+            dgrad = flops_bwd(D_FILTER) - flops_fwd(D_FILTER)
+            executed_factor = (3.0 * flops_fwd(D_FILTER) + 2.0 * dgrad + flops_fwd(D_FILTER)) / flops_per_sample
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
         if os.path.exists(tpath):
@@ -303,7 +308,12 @@ def main():
                          'frac': achieved / PEAK_F16_DENSE_TFLOPS, 'traffic': traffic,
                          'kernel': kernel_name, 'step_ms_hip_events': step_ms,
                          'flops_per_sample': flops_per_sample,
-                         'frac_of_f32_mfma_peak': achieved / PEAK_F32_MFMA_TFLOPS},
+                         'frac_of_f32_mfma_peak': achieved / PEAK_F32_MFMA_TFLOPS,
+                         # what the matrix pipe actually executes: forward products are 3 fp16 MFMAs (hi/lo split), the
+                         # data gradient 2 (hi + lo weights), the weight gradient 1
+                         'executed_frac': achieved * executed_factor / PEAK_F16_DENSE_TFLOPS,
+                         # average HBM rate of the step against the 8 TB/s peak (PMC traffic of this configuration)
+                         'hbm_frac': (traffic / (step_ms * 1e-3) / 8e12) if traffic else None},
         }
         if two_pass is not None:
             line['two_pass'] = two_pass
