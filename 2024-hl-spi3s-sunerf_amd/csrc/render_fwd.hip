@@ -153,9 +153,11 @@ __device__ __forceinline__ void epi_stage_b(PairTmp& t) {
   const f32x2 sv = {t.s0, t.s1};
   t.hi = __builtin_convertvector(sv, half2v);   // one v_cvt_pk_f16_f32 (round to nearest even)
   asm volatile("" : "+v"(t.hi));                 // ... and convert back from the packed word, not from two scalar casts
-  t.r0 = t.s0 - (float)t.hi[0];
-  t.r1 = t.s1 - (float)t.hi[1];
-  asm volatile("" : "+v"(t.hi), "+v"(t.r0), "+v"(t.r1));
+  // remainder x - (float)hi in ONE instruction per element: v_fma_mix_f32 reads the fp16 half of the packed word directly
+  // (fma(hi, -1, x): exact, bit-identical to convert-then-subtract -- tools/probes/probe_fma_mix.hip); saves the two
+  // v_cvt_f32_f16 per pair in an epilogue that is bound by VALU issue slots
+  asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(t.r0) : "v"(t.hi), "v"(t.s0));
+  asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t.r1) : "v"(t.hi), "v"(t.s1));
   if (STASH) {
     const f32x2 cv = {t.c0, t.c1};
     t.cpk = __builtin_convertvector(cv, half2v);
