@@ -14,6 +14,7 @@
 // (computed on the device, no host round trip) and dW / db are multiplied by 1/gscale at the end.
 #include "sunerf_common.h"
 #include "weight_ring.h"
+#include <type_traits>
 #include "../../include/sunerf_hip.h"
 
 namespace {
@@ -123,6 +124,14 @@ __global__ __launch_bounds__(IB_THREADS) void integral_bwd_kernel(
 // The hidden weights are split hi + lo (two MFMAs per k-step): a single fp16 weight (2^-12 relative) is a SYSTEMATIC
 // error that every sample shares and that accumulates over the layers (measured 6e-4 on dW_0 of an 8-layer net);
 // the fp16 rounding of dZ itself is per-sample noise that averages out in the weight gradients.
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 constexpr int DG_WAVES = 4;
 constexpr int DG_THREADS = DG_WAVES * 64;
 
@@ -364,31 +373,36 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_kernel(DgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// dgrad, d_filter <= 256: TWO 32-sample chunks per wave and weight tile
+// dgrad: TWO 32-sample chunks per wave and weight tile
 // ---------------------------------------------------------------------------------------------------------------
 // With one chunk per wave every A fragment pair (hi, lo: 2 KiB of LDS reads) feeds two MFMAs, i.e. 128 KiB of LDS reads
 // per workgroup and tile against 1024 MFMA cycles -- exactly the 128 B/clk the LDS delivers, so the matrix pipe can be at
 // most ~50 % busy.  Here a wave back-propagates two consecutive chunks of its ray at once: each A fragment feeds four
-// MFMAs and the two independent accumulators hide the MFMA dependency latency.  Register budget at D = 256: 4 sets of 16
-// dZ fragments (2 chunks x (layer input, layer output)) = all 256 AGPRs; accumulators, A-fragment ring and a 4-tile cos
-// window per chunk in the VGPRs.  The W^T stream is not staged through registers any more: it is DMA'd page-wise into the
-// same 4-page LDS ring the forward kernel uses (weight_ring.h).
+// MFMAs and the two independent accumulators hide the MFMA dependency latency.  The W^T stream is DMA'd page-wise into the
+// 4-page LDS ring the forward kernel uses (weight_ring.h); stash traffic goes through buffer instructions.
+// Register budget, d <= 256: 4 sets of dZ fragments (2 chunks x (layer input, layer output)) = up to 256 AGPRs.
+// d = 512 (SPILL): one set per chunk fills the 256 AGPRs.  The layer output only goes to the dZ stash (where it has to go
+// anyway) and the LAST tile of a layer -- whose k-step s is the last reader of input fragment s -- pulls fragment s of
+// that output back in as the next layer's input (each lane re-reads exactly the bytes it stored itself).
 template <int D>
 __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_pair_kernel(DgradArgs a) {
   using sunerf_ring::Ring;
+  constexpr bool SPILL = D > 256;
   constexpr int NT = D / 32, KS = D / 16;
+  constexpr int PS = Ring<D>::PAGE_STEPS, NB = KS / PS;            // k-steps per page, pages per tile
   constexpr int PAGE = Ring<D>::PAGE, PIECES = Ring<D>::PIECES;
   constexpr int PF = 2;                             // A fragments requested PF k-steps ahead (across page boundaries)
-  constexpr int ACQ = KS - PF;                      // k-step at which the next page is acquired
-  constexpr int CW = 2;                             // cos window in tiles (per chunk): 2 x 2 x 2 fragments = 32 registers
+  constexpr int ACQ = PS - PF;                      // k-step of a page at which the next page is acquired
+  constexpr int CW = 2;                             // cos window in tiles (per chunk): 2 x 2 x 2 fragments = 32 registers (4: no faster)
   // the epilogue of a tile (dZ = dH * cos, fp16 pack, stash store) is dealt out over the first k-steps of the NEXT tile as
   // 16 pair micro-ops (2 chunks x 8 register pairs); the last tile of a layer produces the next layer's input fragments
   // KS-2 and KS-1, so everything must be done before k-step KS-2
   constexpr int EPI_PER = (16 + (KS - 2) - 1) / (KS - 2);
-  static_assert(Ring<D>::PAGE_STEPS == KS && PIECES <= ACQ && NT % CW == 0 && KS >= 4, "page = one tile; pieces issued before the acquire");
+  static_assert(PIECES <= ACQ && NT % CW == 0 && KS >= 4 && KS % PS == 0, "pieces are issued before the acquire");
+  static_assert(!SPILL || EPI_PER == 1, "reload order assumes one epilogue micro-op per k-step");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // ring of 4 pages
   const StashLayout SL(D, a.n_linear);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 31, h = lane >> 5;
   const int n_act = a.n_linear - 1;
   const int n_chunks = (a.S + 31) >> 5;
@@ -397,9 +411,9 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_pair_kernel(DgradArgs a) 
   const float gscale = gscale_from_bits(*a.g_absmax_bits);
   const char* wT_out = a.packedT;
   const char* wT_hidden = a.packedT + (size_t)NT * 1024;
-  const size_t dz_chunk_bytes = (size_t)n_act * KS * 1024;
+  const unsigned dz_chunk_bytes = (unsigned)n_act * KS * 1024;
   const int n_hidden = a.n_linear - 2;
-  const int n_pages = n_hidden * NT;                 // pages of the W^T stream per chunk pair
+  const int n_pages = n_hidden * NT * NB;            // pages of the W^T stream per chunk pair
   const size_t spare = (size_t)a.n_rays * n_chunks;  // chunk id of the stash slot nobody reads
 
   Ring<D> ring;
@@ -434,39 +448,45 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_pair_kernel(DgradArgs a) 
         si[q] = 32 * c + n;
         valid[q] = have && si[q] < a.S;
       }
-      const char* sb0 = a.stash + cid[0] * SL.chunk_bytes() + lane * 16;
-      const char* sb1 = a.stash + cid[1] * SL.chunk_bytes() + lane * 16;
-      char* dz0 = a.dz_stash + cid[0] * dz_chunk_bytes + lane * 16;
-      char* dz1 = a.dz_stash + cid[1] * dz_chunk_bytes + lane * 16;
+      // wave-uniform resource descriptors: activation stash (cos is read) and dZ stash of the two chunks
+      const Rsrc sb0 = make_rsrc(a.stash + cid[0] * SL.chunk_bytes(), (unsigned)SL.chunk_bytes());
+      const Rsrc sb1 = make_rsrc(a.stash + cid[1] * SL.chunk_bytes(), (unsigned)SL.chunk_bytes());
+      const Rsrc dz0 = make_rsrc(a.dz_stash + cid[0] * (size_t)dz_chunk_bytes, dz_chunk_bytes);
+      const Rsrc dz1 = make_rsrc(a.dz_stash + cid[1] * (size_t)dz_chunk_bytes, dz_chunk_bytes);
 
       // cos window: slot U % CW of chunk q holds the cos fragments of tile U of the layer being consumed; after its use
       // it takes tile U + CW -- of the same layer while U + CW < NT, else tile U + CW - NT of the next layer down
       half8 cw0[2 * CW], cw1[2 * CW];
       {
-        const char* c0 = sb0 + SL.c_off(n_act - 1);
-        const char* c1 = sb1 + SL.c_off(n_act - 1);
+        const int c0 = (int)SL.c_off(n_act - 1);
 #pragma unroll
-        for (int f = 0; f < 2 * CW; ++f) { cw0[f] = *(const half8*)(c0 + f * 1024); cw1[f] = *(const half8*)(c1 + f * 1024); }
+        for (int f = 0; f < 2 * CW; ++f) { cw0[f] = buf_load(sb0, c0 + f * 1024); cw1[f] = buf_load(sb1, c0 + f * 1024); }
       }
-      auto refill = [&](int U, int lc) {   // U is a constant after unrolling
-        const int Un = U + CW < NT ? U + CW : U + CW - NT;
-        const int ln = U + CW < NT ? lc : (lc - 1 >= 0 ? lc - 1 : 0);
-        const size_t off = SL.c_off(ln) + (size_t)(2 * Un) * 1024;
-        cw0[2 * (U % CW)] = *(const half8*)(sb0 + off);
-        cw0[2 * (U % CW) + 1] = *(const half8*)(sb0 + off + 1024);
-        cw1[2 * (U % CW)] = *(const half8*)(sb1 + off);
-        cw1[2 * (U % CW) + 1] = *(const half8*)(sb1 + off + 1024);
+      // window slot `ws` (a literal) is free again after the epilogue of tile Up of the layer whose cos is lc: it takes tile
+      // Up + CW -- of the same layer while Up + CW < NT, else tile Up + CW - NT of the next layer down (clamped to layer 0 at
+      // the very end: never consumed).  Up may be a run-time value (d = 512): only offsets depend on it.
+      auto refill = [&](int ws, int Up, int lc) __attribute__((always_inline)) {
+        const bool same = Up + CW < NT;
+        const int Un = same ? Up + CW : Up + CW - NT;
+        const int ln = same ? lc : (lc - 1 >= 0 ? lc - 1 : 0);
+        const int off = (int)SL.c_off(ln) + (2 * Un) * 1024;
+        cw0[2 * ws] = buf_load(sb0, off);
+        cw0[2 * ws + 1] = buf_load(sb0, off + 1024);
+        cw1[2 * ws] = buf_load(sb1, off);
+        cw1[2 * ws + 1] = buf_load(sb1, off + 1024);
       };
 
       // pending epilogue: accumulators of the tile just finished; t?? collect the packed dZ fragments
       f32x16 prev0, prev1;
       half8 t00, t01, t10, t11;
-      // pair micro-op k (0..15) of the pending tile (layer output offset `lo`, tile Up, cos layer lc): chunk k & 1, register
-      // pair k >> 1.  Finished fragments go to the stash and into the AGPR-resident operand set (y0 / y1).
-      auto epi_op = [&](int k, int Up, int lc, size_t lo, half8* y0, half8* y1) {
+      // pair micro-op k (0..15, a literal) of the pending tile Up (cos window slot ws, cos layer lc, output block offset lo):
+      // chunk k & 1, register pair k >> 1.  Finished fragments go to the stash and, when `y0` is given (then Up must be a
+      // compile-time constant), into the AGPR-resident operand set.  The stores are NOT non-temporal at d = 512: the same
+      // wave reads them back one layer later.
+      auto epi_op = [&](int k, int ws, int Up, int lc, int lo, bool to_regs, half8* y0, half8* y1) __attribute__((always_inline)) {
         const int q = k & 1, pp = k >> 1;                     // constants after unrolling
         const f32x16& acc = q ? prev1 : prev0;
-        const half8& c = (q ? cw1 : cw0)[2 * (Up % CW) + (pp >> 2)];
+        const half8& c = (q ? cw1 : cw0)[2 * ws + (pp >> 2)];
         float v0 = acc[2 * pp] * (float)c[(2 * pp) & 7];
         float v1 = acc[2 * pp + 1] * (float)c[(2 * pp + 1) & 7];
         const f32x2 vv = {v0, v1};
@@ -477,11 +497,14 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_pair_kernel(DgradArgs a) 
         t[(2 * pp + 1) & 7] = pk[1];
         if ((pp & 3) == 3) {                                   // a fragment is complete
           const int f = 2 * Up + (pp >> 2);
-          __builtin_nontemporal_store(t, (half8*)((q ? dz1 : dz0) + lo + (size_t)f * 1024));
-          pin_agpr(t);
-          (q ? y1 : y0)[f] = t;
+          if (SPILL) buf_store(t, q ? dz1 : dz0, lo + f * 1024);
+          else buf_store_nt(t, q ? dz1 : dz0, lo + f * 1024);
+          if (to_regs) {   // (a flag, not `y0 != nullptr`: a null test of a private-array address keeps the array in memory)
+            pin_agpr(t);
+            (q ? y1 : y0)[f] = t;
+          }
         }
-        if (k == 15) refill(Up, lc);                           // both chunks are done with this window slot
+        if (k == 15) refill(ws, Up, lc);                       // both chunks are done with this window slot
       };
 
       half8 dzo0 = {0, 0, 0, 0, 0, 0, 0, 0}, dzo1 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -493,11 +516,12 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_pair_kernel(DgradArgs a) 
         const f32x2 g = *(const f32x2*)(a.g_raw + ((size_t)ray * a.S + si[1]) * 2);
         dzo1[0] = (_Float16)(g[0] * gscale); dzo1[1] = (_Float16)(g[1] * gscale);
       }
-      half8 xa0[KS], xb0[KS], xa1[KS], xb1[KS];
+      constexpr int YK = SPILL ? 1 : KS;                       // d = 512 has no second set
+      half8 xa0[KS], xa1[KS], xb0[YK], xb1[YK];
       // ---- out layer: dH_{L-1} = W_out^T dZ_out, one k-step per tile, A fragments straight from L2; the epilogue of its
       // last tile is left pending for the first hidden tile ----
       {
-        const size_t lo = (size_t)(n_act - 1) * KS * 1024;
+        const int lo = (n_act - 1) * KS * 1024;
 #pragma unroll
         for (int U = 0; U < NT; ++U) {
           const half8 aT = *(const half8*)(wT_out + U * 1024 + lane * 16);
@@ -507,35 +531,45 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_pair_kernel(DgradArgs a) 
           prev0 = acc0; prev1 = acc1;
           if (U < NT - 1 || n_hidden == 0) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) epi_op(k, U, n_act - 1, lo, xa0, xa1);
+            for (int k = 0; k < 16; ++k) epi_op(k, U % CW, U, n_act - 1, lo, true, xa0, xa1);
           }
         }
       }
       // ---- hidden layers, l = n_linear-2 ... 1 : dZ_{l-1} = (W_l^T dZ_l) * cos(Z_{l-1}), both chunks per A fragment ----
-      // x: dZ_l (input; its last two fragments are still being produced by the pending epilogue during tile 0),
-      // y: dZ_{l-1} (output)
-      auto hidden_layer = [&](int l, half8* x0, half8* x1, half8* y0, half8* y1) {
-        const size_t lo = (size_t)(l - 1) * KS * 1024;     // this layer's output block in the dZ stash
-        const size_t lo_in = (size_t)l * KS * 1024;        // the previous layer's (our input's) block
+      // One tile.  x: dZ_l (input; its last two fragments are still being produced by the pending epilogue during the
+      // layer's first tile), y: dZ_{l-1} (output set in registers; nullptr at d = 512, where the output lives in the stash
+      // and replaces x).  `first` / `last` / `ws` (window slot of the PENDING tile) are literals at every call site; U
+      // itself may be a run-time value at d = 512 (only offsets depend on it there).
+      auto tile = [&](int l, int U, bool first, bool last, int ws, half8* x0, half8* x1, half8* y0, half8* y1) __attribute__((always_inline)) {
+        const int lo = (l - 1) * KS * 1024;     // this layer's output block in the dZ stash
+        const int lo_in = l * KS * 1024;        // the previous layer's (our input's) block
+        f32x16 acc0 = {0}, acc1 = {0};
 #pragma unroll
-        for (int U = 0; U < NT; ++U) {
-          f32x16 acc0 = {0}, acc1 = {0};
+        for (int hb = 0; hb < NB; ++hb) {
           const char* nxt = smem + ((slot + 1) & 3) * PAGE + lane * 16;
 #pragma unroll
-          for (int s = 0; s < KS; ++s) {
-            const int r = s % PF;
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(flo[r], x0[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(flo[r], x1[s], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fhi[r], x0[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fhi[r], x1[s], acc1, 0, 0, 0);
-            // pending epilogue: tile U-1 of this layer, or (U == 0) the last tile of the layer above, whose output is our x
+          for (int s = 0; s < PS; ++s) {
+            const int ks = hb * PS + s;
+            const int r = ks % PF;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(flo[r], x0[ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(flo[r], x1[ks], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fhi[r], x0[ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fhi[r], x1[ks], acc1, 0, 0, 0);
+            // pending epilogue: tile U-1 of this layer, or (first) the last tile of the layer above, whose output is our x
 #pragma unroll
             for (int e = 0; e < EPI_PER; ++e) {
-              const int k = s * EPI_PER + e;
+              const int k = ks * EPI_PER + e;
               if (k < 16) {
-                if (U == 0) epi_op(k, NT - 1, l, lo_in, x0, x1);
-                else epi_op(k, U - 1, l - 1, lo, y0, y1);
+                if (first) epi_op(k, ws, NT - 1, l, lo_in, true, x0, x1);
+                else epi_op(k, ws, U - 1, l - 1, lo, !SPILL, y0, y1);
               }
+            }
+            if (SPILL && last && ks < KS - 2) {
+              // last tile: k-step ks was the last reader of input fragment ks -> it becomes fragment ks of this layer's
+              // output (stored by the epilogue of tile ks/2: at the latest by this tile's k-step 15, for ks = 28, 29)
+              x0[ks] = buf_load(dz0, lo + ks * 1024);
+              x1[ks] = buf_load(dz1, lo + ks * 1024);
+              pin_agpr(x0[ks]); pin_agpr(x1[ks]);
             }
             if (s < PIECES) {   // page + 3 of the stream -> the ring slot everyone left at the last acquire
               if (s == 0) ring.template issue_piece<0>();
@@ -548,17 +582,14 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_pair_kernel(DgradArgs a) 
               if (s == 7 && PIECES > 7) ring.template issue_piece<(PIECES > 7 ? 7 : 0)>();
             }
             if (s == ACQ) {
-              // next page: this wave's pieces of it have landed once at most the 2 younger pages (and whatever was issued
-              // after them) are outstanding; then everyone's.  Raw barrier: the cos / dZ traffic stays in flight.
-#ifndef DG_ACQ_N
-#define DG_ACQ_N (2 * PIECES)
-#endif
-              asm volatile("s_waitcnt vmcnt(%0)" :: "i"(DG_ACQ_N) : "memory");
+              // next page: this wave's pieces of it have landed once at most the 2 younger pages (and whatever was
+              // issued after them) are outstanding; then everyone's.  Raw barrier: the cos / dZ traffic stays in flight.
+              asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * PIECES) : "memory");
               __builtin_amdgcn_s_barrier();
             }
             {
               const int sn = s + PF;
-              const char* q = sn < KS ? cur + sn * 2048 : nxt + (sn - KS) * 2048;
+              const char* q = sn < PS ? cur + sn * 2048 : nxt + (sn - PS) * 2048;
               fhi[r] = *(const half8*)q;
               flo[r] = *(const half8*)(q + 1024);
             }
@@ -566,22 +597,45 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_pair_kernel(DgradArgs a) 
           }
           slot = (slot + 1) & 3;
           cur = nxt;
-          prev0 = acc0; prev1 = acc1;
+        }
+        prev0 = acc0; prev1 = acc1;
+      };
+      auto hidden_layer = [&](int l, half8* x0, half8* x1, half8* y0, half8* y1) __attribute__((always_inline)) {
+        if constexpr (SPILL) {
+          // four tile bodies instead of sixteen: first, a run-time loop over pairs of middle tiles (window slots 0, 1), last
+          static_assert(CW == 2 && NT % 2 == 0, "tile pairing follows the two-slot cos window");
+          tile(l, 0, true, false, (NT - 1) % CW, x0, x1, x0, x1);
+          for (int U = 1; U < NT - 1; U += 2) {
+            tile(l, U, false, false, 0, x0, x1, x0, x1);       // pending: tile U - 1 (even)
+            tile(l, U + 1, false, false, 1, x0, x1, x0, x1);   // pending: tile U (odd)
+          }
+          tile(l, NT - 1, false, true, 0, x0, x1, x0, x1);
+        } else {
+#pragma unroll
+          for (int U = 0; U < NT; ++U) tile(l, U, U == 0, false, (U == 0 ? NT - 1 : U - 1) % CW, x0, x1, y0, y1);
         }
       };
-      int l = a.n_linear - 2;
-      int last = 0;   // which set holds the output of the last hidden layer: 0 = xb, 1 = xa
-      for (; l - 1 >= 1; l -= 2) {
-        hidden_layer(l, xa0, xa1, xb0, xb1);
-        hidden_layer(l - 1, xb0, xb1, xa0, xa1);
-        last = 1;
-      }
-      if (l >= 1) { hidden_layer(l, xa0, xa1, xb0, xb1); last = 0; }
-      if (n_hidden > 0) {   // flush: the last tile of layer 1 has no successor in this pair
+      if constexpr (SPILL) {
+        for (int l = a.n_linear - 2; l >= 1; --l) hidden_layer(l, xa0, xa1, xa0, xa1);
+        if (n_hidden > 0) {   // flush: the last tile of layer 1 has no successor in this pair
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          if (last) epi_op(k, NT - 1, 0, 0, xa0, xa1);
-          else epi_op(k, NT - 1, 0, 0, xb0, xb1);
+          for (int k = 0; k < 16; ++k) epi_op(k, (NT - 1) % CW, NT - 1, 0, 0, false, xa0, xa1);
+        }
+      } else {
+        int l = a.n_linear - 2;
+        int last = 0;   // which set holds the output of the last hidden layer: 0 = xb, 1 = xa
+        for (; l - 1 >= 1; l -= 2) {
+          hidden_layer(l, xa0, xa1, xb0, xb1);
+          hidden_layer(l - 1, xb0, xb1, xa0, xa1);
+          last = 1;
+        }
+        if (l >= 1) { hidden_layer(l, xa0, xa1, xb0, xb1); last = 0; }
+        if (n_hidden > 0) {   // flush: the last tile of layer 1 has no successor in this pair
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            if (last) epi_op(k, (NT - 1) % CW, NT - 1, 0, 0, true, xa0, xa1);
+            else epi_op(k, (NT - 1) % CW, NT - 1, 0, 0, true, xb0, xb1);
+          }
         }
       }
     }
@@ -693,19 +747,11 @@ static int launch_dgrad(const DgradArgs& a, hipStream_t stream) {
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const unsigned grid = (unsigned)(n_groups < cus ? n_groups : cus);
-  if constexpr (D <= 256) {   // two chunks per wave + LDS-DMA weight ring
-    const size_t lds = (size_t)sunerf_ring::Ring<D>::RING;
-    hipError_t e = hipFuncSetAttribute((const void*)dgrad_pair_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    SUNERF_CLEAR_ERROR();
-    hipLaunchKernelGGL(dgrad_pair_kernel<D>, dim3(grid), dim3(DG_THREADS), lds, stream, a);
-  } else {                    // d = 512: one chunk per wave, register-staged half tiles
-    const size_t lds = 2 * (size_t)16 * 2048;
-    hipError_t e = hipFuncSetAttribute((const void*)dgrad_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    SUNERF_CLEAR_ERROR();
-    hipLaunchKernelGGL(dgrad_kernel<D>, dim3(grid), dim3(DG_THREADS), lds, stream, a);
-  }
+  const size_t lds = (size_t)sunerf_ring::Ring<D>::RING;
+  hipError_t e = hipFuncSetAttribute((const void*)dgrad_pair_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  SUNERF_CLEAR_ERROR();
+  hipLaunchKernelGGL(dgrad_pair_kernel<D>, dim3(grid), dim3(DG_THREADS), lds, stream, a);
   SUNERF_CHECK_LAUNCH();
   return 0;
 }

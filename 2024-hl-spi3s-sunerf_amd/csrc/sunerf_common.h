@@ -102,3 +102,25 @@ __host__ __device__ inline int acc_row(int g, int h) { return (g & 3) + 8 * (g >
     hipError_t e__ = hipGetLastError();               \
     if (e__ != hipSuccess) return (int)e__;           \
   } while (0)
+
+#if defined(__HIPCC__)
+// Stash and scratch traffic goes through BUFFER instructions: wave-uniform base in a scalar resource descriptor, the lane
+// part (lane * 16) as the one VGPR offset, the many constant fragment offsets as scalar offsets / immediates.  With per-lane
+// 64-bit pointers the compiler materialises one VGPR pair per fragment address, hoists them all out of the chunk loop and
+// spills them (200 spilled VGPRs at d = 512).
+using Rsrc = __amdgpu_buffer_rsrc_t;
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned lane_off() { return (threadIdx.x & 63u) * 16u; }
+__device__ __forceinline__ Rsrc make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_store(half8 v, Rsrc r, int off) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)lane_off(), off, 0);
+}
+__device__ __forceinline__ void buf_store_nt(half8 v, Rsrc r, int off) {   // non-temporal: written once, read by another kernel
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)lane_off(), off, 2);
+}
+__device__ __forceinline__ half8 buf_load(Rsrc r, int off) {
+  return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off(), off, 0));
+}
+#endif
