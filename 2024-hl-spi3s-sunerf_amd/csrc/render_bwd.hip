@@ -543,6 +543,8 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_pair_kernel(DgradArgs a) 
       auto tile = [&](int l, int U, bool first, bool last, int ws, half8* x0, half8* x1, half8* y0, half8* y1) __attribute__((always_inline)) {
         const int lo = (l - 1) * KS * 1024;     // this layer's output block in the dZ stash
         const int lo_in = l * KS * 1024;        // the previous layer's (our input's) block
+        constexpr int RL = 3;
+        half8 rl0[RL], rl1[RL];
         f32x16 acc0 = {0}, acc1 = {0};
 #pragma unroll
         for (int hb = 0; hb < NB; ++hb) {
@@ -564,12 +566,20 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_pair_kernel(DgradArgs a) 
                 else epi_op(k, ws, U - 1, l - 1, lo, !SPILL, y0, y1);
               }
             }
-            if (SPILL && last && ks < KS - 2) {
+            if (SPILL && last) {
               // last tile: k-step ks was the last reader of input fragment ks -> it becomes fragment ks of this layer's
-              // output (stored by the epilogue of tile ks/2: at the latest by this tile's k-step 15, for ks = 28, 29)
-              x0[ks] = buf_load(dz0, lo + ks * 1024);
-              x1[ks] = buf_load(dz1, lo + ks * 1024);
-              pin_agpr(x0[ks]); pin_agpr(x1[ks]);
+              // output (stored by the epilogue of tile ks/2: at the latest by this tile's k-step 15, for ks = 28, 29).
+              // Requested at k-step ks, committed to the operand registers RL k-steps later (an immediate commit would
+              // park the wave for an L2 round trip in every k-step).
+              if (ks >= RL && ks - RL < KS - 2) {
+                x0[ks - RL] = rl0[(ks - RL) % RL];
+                x1[ks - RL] = rl1[(ks - RL) % RL];
+                pin_agpr(x0[ks - RL]); pin_agpr(x1[ks - RL]);
+              }
+              if (ks < KS - 2) {
+                rl0[ks % RL] = buf_load(dz0, lo + ks * 1024);
+                rl1[ks % RL] = buf_load(dz1, lo + ks * 1024);
+              }
             }
             if (s < PIECES) {   // page + 3 of the stream -> the ring slot everyone left at the last acquire
               if (s == 0) ring.template issue_piece<0>();
@@ -597,6 +607,15 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_pair_kernel(DgradArgs a) 
           }
           slot = (slot + 1) & 3;
           cur = nxt;
+        }
+        if (SPILL && last) {   // the last RL requests
+#pragma unroll
+          for (int ks = KS; ks < KS + RL; ++ks)
+            if (ks - RL >= 0 && ks - RL < KS - 2) {
+              x0[ks - RL] = rl0[(ks - RL) % RL];
+              x1[ks - RL] = rl1[(ks - RL) % RL];
+              pin_agpr(x0[ks - RL]); pin_agpr(x1[ks - RL]);
+            }
         }
         prev0 = acc0; prev1 = acc1;
       };

@@ -276,6 +276,8 @@ struct Mlp {
     constexpr int PER = (8 + EPI_STEPS - 1) / EPI_STEPS;   // pair micro-ops per k-step
     constexpr int ACQ = (PAGE_STEPS - PF) % PAGE_STEPS;    // page phase at which the next page is acquired
     half8 ch0, ch1;                                        // fp16 cos fragments (training)
+    constexpr int RL = 3;                                  // RELOAD: k-steps between the request of a fragment and its use
+    half8 rl_hi[RL], rl_lo[RL];
 #pragma unroll
     for (int s = 0; s < KIN; ++s) {
       const int r = (T0 + s) % PF;
@@ -303,10 +305,18 @@ struct Mlp {
         for (int q = 0; q < PER; ++q)
           if (s * PER + q < 8) epi_stage_c<STASH, SPILL_OUT>(t[q], s * PER + q, yh0, yl0, yh1, yl1, ch0, ch1, st, st_off, cos_delta, sc, sc_out_off);
       }
-      if (RELOAD && s < KIN - 2) {   // fragments KIN-2, KIN-1 arrive through the carry epilogue of the next layer's first tile
-        xhi[s] = buf_load(sc, s * 2048);
-        xlo[s] = buf_load(sc, s * 2048 + 1024);
-        pin_agpr(xhi[s]); pin_agpr(xlo[s]);
+      if (RELOAD) {   // fragments KIN-2, KIN-1 arrive through the carry epilogue of the next layer's first tile
+        // requested at k-step s, moved into the operand registers RL k-steps later: committing right away would park the
+        // wave for a whole L2 round trip in every k-step of the tile
+        if (s >= RL && s - RL < KIN - 2) {
+          xhi[s - RL] = rl_hi[(s - RL) % RL];
+          xlo[s - RL] = rl_lo[(s - RL) % RL];
+          pin_agpr(xhi[s - RL]); pin_agpr(xlo[s - RL]);
+        }
+        if (s < KIN - 2) {
+          rl_hi[s % RL] = buf_load(sc, s * 2048);
+          rl_lo[s % RL] = buf_load(sc, s * 2048 + 1024);
+        }
       }
       {
         const int phase = (T0 + s) % PAGE_STEPS;
@@ -328,6 +338,15 @@ struct Mlp {
         load_frag(p, r, rs);
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if (RELOAD) {   // the last RL requests
+#pragma unroll
+      for (int s = KIN; s < KIN + RL; ++s)
+        if (s - RL >= 0 && s - RL < KIN - 2) {
+          xhi[s - RL] = rl_hi[(s - RL) % RL];
+          xlo[s - RL] = rl_lo[(s - RL) % RL];
+          pin_agpr(xhi[s - RL]); pin_agpr(xlo[s - RL]);
+        }
     }
     if (RS0 < 0) {
       p.rstep += KIN;
