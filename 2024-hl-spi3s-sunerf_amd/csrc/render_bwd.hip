@@ -2,13 +2,13 @@
 //
 //   loss gradients w.r.t. image (N) and regularization (N,S)
 //     -> integral_bwd_kernel : d/d raw of emission.py:14-54 + base_tracing.py:43-44,108        -> g_raw (N,S,2)
-//     -> dgrad_kernel        : back-propagation through the sine MLP (model.py:44-57), per 32-sample chunk:
+//     -> dgrad_pair_kernel   : back-propagation through the sine MLP (model.py:44-57), two 32-sample chunks per wave:
 //                              dZ_l = (W_{l+1}^T dZ_{l+1}) * cos(Z_l), written to the dZ stash (fp16 fragments)
 //     -> wgrad (wgrad.hip)   : dW_l = sum_samples dZ_l H_{l-1}^T,  db_l = sum_samples dZ_l
 // No gradient flows to the ray geometry / sample positions (sampling.py:120 detaches the resampled z and the
 // stratified z has no parameters), so layer 0 needs no data gradient.
 //
-// Numerics: the matrix products use single fp16 operands (fp32 accumulate): the reference tolerance for gradients
+// Numerics: dZ and the activations enter the matrix products as single fp16 operands, W^T as hi + lo (fp32 accumulate): the reference tolerance for gradients
 // is 1e-3 relative per tensor and the rounding errors (2^-12 relative, unbiased) average out over the samples.  fp16 has
 // a narrow exponent range, so g_raw is multiplied by a power of two `gscale` chosen from max|g_raw| of the batch
 // (computed on the device, no host round trip) and dW / db are multiplied by 1/gscale at the end.
@@ -163,212 +163,6 @@ __device__ __forceinline__ void dz_tile(const f32x16& acc, const half8& c0, cons
   for (int j = 0; j < 8; ++j) {
     d0[j] = (_Float16)(acc[j] * (float)c0[j]);
     d1[j] = (_Float16)(acc[8 + j] * (float)c1[j]);
-  }
-}
-
-template <int D>
-__global__ __launch_bounds__(DG_THREADS, 1) void dgrad_kernel(DgradArgs a) {
-  constexpr int NT = D / 32, KS = D / 16;
-  constexpr int HB = KS < 16 ? KS : 16;        // k-steps per staged weight block
-  constexpr int NB = KS / HB;                  // blocks per (layer, tile): 2 at D = 512 (a 64 KiB tile would not double-buffer)
-  constexpr int BLK = HB * 2048;               // one block of W^T: HB k-steps x (hi 1 KiB + lo 1 KiB)
-  constexpr int VEC = BLK / 16 / DG_THREADS;   // 16-byte vectors per thread and block
-  constexpr int PD = 2;                        // weight blocks prefetched into registers (divides NT * NB: static rotation)
-  // cos fragments: D <= 256 keeps two whole layers in registers (ca / cb alternate); D = 512 keeps ONE sliding window of
-  // CW tiles (a layer is 128 registers there), refilled CW tiles ahead across the layer boundary
-  constexpr bool WINDOW = D > 256;
-  constexpr int CW = 8;
-  static_assert(BLK % (16 * DG_THREADS) == 0 && (NT * NB) % PD == 0, "block must split evenly over the threads");
-  static_assert(!WINDOW || (NT % CW == 0 && NB == PD), "window / stage rotation must be static");
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x BLK
-  const StashLayout SL(D, a.n_linear);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = lane & 31, h = lane >> 5;
-  const int n_act = a.n_linear - 1;
-  const int n_chunks = (a.S + 31) >> 5;
-  const int64_t n_groups = (a.n_rays + DG_WAVES - 1) / DG_WAVES;
-  const float gscale = gscale_from_bits(*a.g_absmax_bits);
-  const char* wT_out = a.packedT;                               // NT x 1 KiB (hi only: 2 output columns)
-  const char* wT_hidden = a.packedT + (size_t)NT * 1024;        // (n_linear-2) layers x NT blocks, l descending
-  const size_t dz_chunk_bytes = (size_t)n_act * KS * 1024;
-  const int n_hidden = a.n_linear - 2;
-  const int n_blocks = n_hidden * NT * NB;
-
-  for (int64_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
-    const int64_t ray_raw = group * DG_WAVES + wave;
-    const bool ray_ok = ray_raw < a.n_rays;
-    const int64_t ray = ray_ok ? ray_raw : a.n_rays - 1;
-    for (int c = 0; c < n_chunks; ++c) {
-      const int i = 32 * c + n;
-      const bool valid = ray_ok && i < a.S;
-      // spare chunk for waves without a ray / chunk id of this wave
-      const size_t chunk_id = ray_ok ? (size_t)ray_raw * n_chunks + c : (size_t)a.n_rays * n_chunks;
-      const char* sbase = a.stash + chunk_id * SL.chunk_bytes() + lane * 16;
-      char* dzbase = a.dz_stash + chunk_id * dz_chunk_bytes + lane * 16;
-
-      // weight blocks 0..PD-1 of the chunk's stream -> registers (consumed through the LDS double buffer below)
-      f32x4 stage[PD][VEC];
-#pragma unroll
-      for (int p = 0; p < PD; ++p)
-        if (p < n_blocks) {
-#pragma unroll
-          for (int v = 0; v < VEC; ++v)
-            stage[p][v] = *(const f32x4*)(wT_hidden + (size_t)p * BLK + (size_t)(v * DG_THREADS + tid) * 16);
-        }
-      // cos fragments of the first two layers this chunk back-propagates through (one layer = 2*NT fragments ahead)
-      half8 ca[WINDOW ? 2 * CW : KS], cb[WINDOW ? 1 : KS];
-      {
-        const char* c1 = sbase + SL.c_off(n_act - 1);
-#pragma unroll
-        for (int s = 0; s < (WINDOW ? 2 * CW : KS); ++s) ca[s] = *(const half8*)(c1 + s * 1024);
-        if (!WINDOW && n_act >= 2) {
-          const char* c2 = sbase + SL.c_off(n_act - 2);
-#pragma unroll
-          for (int s = 0; s < KS; ++s) cb[s] = *(const half8*)(c2 + s * 1024);
-        }
-      }
-      // window mode: after its use by tile U of the layer that consumes cos_lc, slot U % CW takes tile U + CW -- of the
-      // same layer while U + CW < NT, else tile U + CW - NT of cos_{lc-1} (clamped to layer 0 at the end: never consumed)
-      auto window_refill = [&](int U, int lc) {
-        const int Un = U + CW < NT ? U + CW : U + CW - NT;
-        const int ln = U + CW < NT ? lc : (lc - 1 >= 0 ? lc - 1 : 0);
-        const char* cn = sbase + SL.c_off(ln);
-        ca[2 * (U % CW)] = *(const half8*)(cn + (2 * Un) * 1024);
-        ca[2 * (U % CW) + 1] = *(const half8*)(cn + (2 * Un + 1) * 1024);
-      };
-      // dZ of the output layer as a B fragment: K slot 0 / 1 = d loss / d raw[..., 0 / 1]
-      half8 dz_out = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (valid && h == 0) {
-        const f32x2 g = *(const f32x2*)(a.g_raw + ((size_t)ray * a.S + i) * 2);
-        dz_out[0] = (_Float16)(g[0] * gscale);
-        dz_out[1] = (_Float16)(g[1] * gscale);
-      }
-      half8 xa[KS], xb[KS];
-      // ---- out layer: dH_{L-1} = W_out^T dZ_out, one k-step per tile, A fragments straight from L2 ----
-      {
-        char* dzl = dzbase + (size_t)(n_act - 1) * KS * 1024;
-#pragma unroll
-        for (int U = 0; U < NT; ++U) {
-          const half8 aT = *(const half8*)(wT_out + U * 1024 + lane * 16);
-          f32x16 acc = {0};
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aT, dz_out, acc, 0, 0, 0);
-          half8 d0, d1;
-          if constexpr (WINDOW) {
-            dz_tile(acc, ca[2 * (U % CW)], ca[2 * (U % CW) + 1], d0, d1);
-            window_refill(U, n_act - 1);
-          } else {
-            dz_tile(acc, ca[2 * U], ca[2 * U + 1], d0, d1);
-          }
-          __builtin_nontemporal_store(d0, (half8*)(dzl + (2 * U) * 1024));
-          __builtin_nontemporal_store(d1, (half8*)(dzl + (2 * U + 1) * 1024));
-          pin_agpr(d0); pin_agpr(d1);
-          xa[2 * U] = d0; xa[2 * U + 1] = d1;
-        }
-      }
-      if (n_blocks > 0) {   // first block -> LDS buffer 0
-        __syncthreads();    // previous chunk's readers of buffer 0 are done
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) *(f32x4*)(smem + (size_t)(v * DG_THREADS + tid) * 16) = stage[0][v];
-        __syncthreads();
-      }
-      // ---- hidden layers, l = n_linear-2 ... 1 : dZ_{l-1} = (W_l^T dZ_l) * cos(Z_{l-1}) ----
-      // per tile: block blk is read from LDS buffer blk&1; block blk+1 (in registers since PD tiles) is written to the
-      // other buffer at the end of the tile; block blk+PD is requested from L2; the cos fragments of the layer AFTER
-      // the next one are requested one whole layer (2*NT fragments) ahead of their use.
-      int blk = 0;
-      // consumes dZ_l (x) and cos_{l-1} (cc), produces dZ_{l-1} (y); refills cc with cos_{l-3} for the layer after next
-      auto hidden_layer = [&](int l, const half8* x, half8* y, half8* cc) {
-        char* dzl = dzbase + (size_t)(l - 1) * KS * 1024;
-        const bool more_cos = l - 3 >= 0;
-        const char* cnext = sbase + SL.c_off(more_cos ? l - 3 : 0);
-#pragma unroll
-        for (int U = 0; U < NT; ++U) {
-          f32x16 acc = {0};
-#pragma unroll
-          for (int hb = 0; hb < NB; ++hb) {
-            const char* buf = smem + (blk & 1) * BLK;
-            {
-              // unconditional (the last PD blocks of a chunk re-read the final block): a branch around these loads makes
-              // hipcc's s_waitcnt insertion fall back to a conservative count that drains the prefetches every tile
-              const int nb = min(blk + PD, n_blocks - 1);
-#pragma unroll
-              for (int v = 0; v < VEC; ++v)   // block blk has left this stage slot (written to LDS one block ago)
-                stage[(U * NB + hb) % PD][v] =
-                    *(const f32x4*)(wT_hidden + (size_t)nb * BLK + (size_t)(v * DG_THREADS + tid) * 16);
-            }
-            {
-              // A fragments PF k-steps ahead of their MFMAs; sched_barrier pins the reads there (hipcc would otherwise
-              // sink each read next to its use and expose the LDS latency on every k-step)
-              constexpr int PF = HB < 4 ? HB : 4;
-              const char* fb = buf + lane * 16;
-              half8 fhi[PF], flo[PF];
-#pragma unroll
-              for (int s = 0; s < PF; ++s) { fhi[s] = *(const half8*)(fb + s * 2048); flo[s] = *(const half8*)(fb + s * 2048 + 1024); }
-              __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-              for (int s = 0; s < HB; ++s) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(flo[s % PF], x[hb * HB + s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fhi[s % PF], x[hb * HB + s], acc, 0, 0, 0);
-                if (s + PF < HB) {
-                  fhi[s % PF] = *(const half8*)(fb + (s + PF) * 2048);
-                  flo[s % PF] = *(const half8*)(fb + (s + PF) * 2048 + 1024);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-              }
-            }
-            if (hb == NB - 1) {
-              half8 d0, d1;
-              if constexpr (WINDOW) {
-                dz_tile(acc, cc[2 * (U % CW)], cc[2 * (U % CW) + 1], d0, d1);
-                window_refill(U, l - 1);
-              } else {
-                dz_tile(acc, cc[2 * U], cc[2 * U + 1], d0, d1);
-                // this tile's cos registers are free again: refill (unconditionally, see above; the last layers of a
-                // chunk re-read layer 0's fragments, which nobody consumes)
-                cc[2 * U] = *(const half8*)(cnext + (2 * U) * 1024);
-                cc[2 * U + 1] = *(const half8*)(cnext + (2 * U + 1) * 1024);
-              }
-              __builtin_nontemporal_store(d0, (half8*)(dzl + (2 * U) * 1024));
-              __builtin_nontemporal_store(d1, (half8*)(dzl + (2 * U + 1) * 1024));
-              pin_agpr(d0); pin_agpr(d1);
-              y[2 * U] = d0; y[2 * U + 1] = d1;
-            }
-#pragma unroll
-            for (int v = 0; v < VEC; ++v)
-              *(f32x4*)(smem + ((blk + 1) & 1) * BLK + (size_t)(v * DG_THREADS + tid) * 16) = stage[(U * NB + hb + 1) % PD][v];
-            // LDS hand-off only: __syncthreads() would also drain every outstanding global load / store (vmcnt(0)) and
-            // with it the cos / weight prefetches that are meant to stay in flight across tiles
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            ++blk;
-          }
-        }
-      };
-      // layer l uses cos_{l-1}: ca holds cos_{n_act-1} (used by the out layer) -> the first hidden layer l = n_act - 1
-      // uses cos_{n_act-2} = cb, the second ca (refilled with cos_{n_act-3} by the out layer below), and so on.
-      int l = a.n_linear - 2;
-      if constexpr (WINDOW) {
-        for (; l - 1 >= 1; l -= 2) {
-          hidden_layer(l, xa, xb, ca);
-          hidden_layer(l - 1, xb, xa, ca);
-        }
-        if (l >= 1) hidden_layer(l, xa, xb, ca);
-        continue;
-      }
-      if (l >= 1) {
-        // refill ca (free since the out layer) with the cos of the second hidden layer
-        if (l - 2 >= 0) {
-          const char* c3 = sbase + SL.c_off(l - 2);
-#pragma unroll
-          for (int s = 0; s < KS; ++s) ca[s] = *(const half8*)(c3 + s * 1024);
-        }
-      }
-      for (; l - 1 >= 1; l -= 2) {
-        hidden_layer(l, xa, xb, cb);
-        hidden_layer(l - 1, xb, xa, ca);
-      }
-      if (l >= 1) hidden_layer(l, xa, xb, cb);
-    }
   }
 }
 
