@@ -14,7 +14,6 @@
 // (computed on the device, no host round trip) and dW / db are multiplied by 1/gscale at the end.
 #include "sunerf_common.h"
 #include "weight_ring.h"
-#include <type_traits>
 #include "../../include/sunerf_hip.h"
 
 namespace {
@@ -124,14 +123,6 @@ __global__ __launch_bounds__(IB_THREADS) void integral_bwd_kernel(
 // The hidden weights are split hi + lo (two MFMAs per k-step): a single fp16 weight (2^-12 relative) is a SYSTEMATIC
 // error that every sample shares and that accumulates over the layers (measured 6e-4 on dW_0 of an 8-layer net);
 // the fp16 rounding of dZ itself is per-sample noise that averages out in the weight gradients.
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
 constexpr int DG_WAVES = 4;
 constexpr int DG_THREADS = DG_WAVES * 64;
 
