@@ -82,6 +82,51 @@ def test_large_batch_properties(ops):
     assert ((out['image'].cpu()[idx] - ref['image']).abs().max() / ref['image'].abs().max()).item() < 1e-4
 
 
+def test_training_batch_properties(ops):
+    """BASELINE-sized training launch (32768 rays x 128 samples, 8 x 256 MLP) through forward-with-stash, integral backward,
+    dgrad and wgrad: gradients are additive over disjoint ray blocks (second block accumulated on top of the first equals
+    the whole batch), linear in the upstream gradient, and a random subset of rays reproduces the oracle's gradient."""
+    from sunerf_hip.rays import observer_rays
+    params, packed = _packed(ops, d_filter=256, n_layers=8, seed=7)
+    o, d = observer_rays(1024, row_start=496, row_end=528, device='cuda')       # 32 rows through the disk
+    n = o.shape[0]
+    gen = torch.Generator().manual_seed(4)
+    t = torch.rand(n, generator=gen).cuda()
+    g_image = (torch.randn(n, generator=gen) * 1e-4).cuda()
+    z = ops.sample_z(ops.SAMPLER_STRATIFIED, o, d, torch.linspace(0, 1, 128).cuda(), 1.3, 1.0)
+
+    def grads(sl, scale=1.0, into=None):
+        fwd = ops.emission_render_fwd(packed, o[sl], d[sl], t[sl], z[sl], 1.2, want_epilogues=True, training=True)
+        gW = into[0] if into else [torch.empty(W.shape, device='cuda') for W, _ in params]
+        gb = into[1] if into else [torch.empty(b.shape, device='cuda') for _, b in params]
+        ops.emission_render_bwd(packed, o[sl], d[sl], z[sl], fwd['raw'], fwd['stash'], g_image[sl] * scale, None, 3e-7, 1.2,
+                                gW, gb, accumulate=into is not None)
+        return gW, gb
+
+    whole = grads(slice(0, n))
+    halves = grads(slice(0, n // 2))
+    grads(slice(n // 2, n), into=halves)
+    scaled = grads(slice(0, n), scale=8.0)       # also moves the on-device fp16 gradient scale by 3 binades
+    for i, (W, Wh, Ws) in enumerate(zip(whole[0], halves[0], scaled[0])):
+        assert torch.isfinite(W).all()
+        assert ((W - Wh).norm() / W.norm()).item() < 1e-3, i
+    # linear in g_image for the image part (the constant regularization gradient does not scale): compare differences
+    eighth = grads(slice(0, n), scale=0.0)
+    for i, (W, Ws, W0) in enumerate(zip(whole[0], scaled[0], eighth[0])):
+        assert (((Ws - W0) - 8.0 * (W - W0)).norm() / (8.0 * (W - W0)).norm()).item() < 2e-3, i
+    # a block of 96 rays against the CPU oracle's autograd
+    idx = slice(n // 2 - 48, n // 2 + 48)
+    sub = grads(idx)
+    leaves = [(W.clone().requires_grad_(True), b.clone().requires_grad_(True)) for W, b in params]
+    out = orc.render_pass(leaves, o[idx].cpu(), d[idx].cpu(), t[idx].cpu()[:, None], z[idx].cpu())
+    dist_pts = out['points'].pow(2).sum(-1).pow(0.5)
+    reg = torch.relu(dist_pts - 1.2) * (1 - out['regularizing_quantity'])
+    ((out['image'][:, 0] * g_image[idx].cpu()).sum() + 3e-7 * reg.sum()).backward()
+    for i, ((W, b), gW, gb) in enumerate(zip(leaves, sub[0], sub[1])):
+        assert ((gW.cpu() - W.grad).norm() / W.grad.norm()).item() < 1e-3, i
+        assert ((gb.cpu() - b.grad).norm() / b.grad.norm()).item() < 1e-3, i
+
+
 def test_unsupported_width_is_a_clear_error():
     from sunerf.model.model import NeRF
     with pytest.raises(ValueError, match='d_filter'):
