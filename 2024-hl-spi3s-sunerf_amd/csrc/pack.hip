@@ -11,6 +11,34 @@ struct PackArgs {
   char* packed;
 };
 
+// max |w| (after the 1/(2 pi) scaling of the non-output layers) of every hidden / out layer -> absmax[l] (float bits)
+__global__ void pack_absmax_kernel(PackArgs a) {
+  const PackedLayout L(a.D, a.n_linear);
+  unsigned* absmax = (unsigned*)(a.packed + L.absmax_off());
+  const int l = 1 + blockIdx.y;
+  const int rows = (l == a.n_linear - 1) ? a.d_out : a.D;
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)rows * a.D; i += (size_t)gridDim.x * blockDim.x) {
+    float w = a.W[l][i];
+    if (l < a.n_linear - 1) w *= 0.15915494309189535f;
+    m = fmaxf(m, fabsf(w));
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if ((threadIdx.x & 63) == 0 && m > 0.f && m < INFINITY) atomicMax(absmax + l, __float_as_uint(m));
+}
+
+__device__ __forceinline__ int scale_exponent(unsigned absmax_bits) {
+  const float m = __uint_as_float(absmax_bits);
+  if (!(m > 0.f)) return 0;
+  int e;
+  frexpf(m, &e);            // m = f 2^e, f in [0.5, 1)  =>  |w| < 2^e
+  return 8 - e;
+}
+__device__ __forceinline__ unsigned char to_fp8(float x) {   // OCP e4m3, round to nearest even, saturating
+  return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(x, 0.f, 0, false) & 0xff);
+}
+
 // one thread per (hi, lo) pair of the image
 __global__ void pack_mlp_kernel(PackArgs a) {
   const PackedLayout L(a.D, a.n_linear);
@@ -54,6 +82,17 @@ __global__ void pack_mlp_kernel(PackArgs a) {
   if (col >= 0 && row < n_rows) w = a.W[l][(size_t)row * in_dim + col];
   if (l < a.n_linear - 1) w *= 0.15915494309189535f;   // pre-activation in revolutions for v_sin_f32
   const _Float16 hi = (_Float16)w;                  // round to nearest
+  if (l >= 1 && PackedLayout::fp8c(a.D)) {          // fp8c format (sunerf_common.h)
+    const int sh = scale_exponent(((const unsigned*)(a.packed + L.absmax_off()))[l]);
+    if (U == 0 && s == 0 && lane == 0 && e == 0) ((int*)(a.packed + L.scale_off()))[l] = sh;
+    char* grp = a.packed + L.block_off(l, U) + (size_t)(s >> 2) * SUNERF_GROUP_BYTES;
+    const int sl = s & 3;
+    *(_Float16*)(grp + sl * 1024 + lane * 16 + e * 2) = hi;
+    const size_t byte = (size_t)(sl >> 1) * 1024 + lane * 16 + (sl & 1) * 8 + e;
+    grp[4096 + byte] = (char)to_fp8(ldexpf(w - (float)hi, sh + 11));
+    grp[6144 + byte] = (char)to_fp8(ldexpf((float)hi, sh));
+    return;
+  }
   const _Float16 lo = (_Float16)(w - (float)hi);    // exact remainder, rounded to nearest (may be subnormal)
   _Float16* blk = (_Float16*)(a.packed + L.block_off(l, U));
   blk[((size_t)(s * 2 + 0) * 64 + lane) * 8 + e] = hi;
@@ -85,6 +124,12 @@ extern "C" int sunerf_pack_mlp(const float* const* weights_host, const float* co
   const int threads = 256;
   const unsigned blocks = (unsigned)((total + threads - 1) / threads);
   SUNERF_CLEAR_ERROR();
+  if (PackedLayout::fp8c(d_filter)) {
+    hipError_t e = hipMemsetAsync(a.packed + L.scale_off(), 0, 128, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(pack_absmax_kernel, dim3(64, n_linear - 1), dim3(256), 0, (hipStream_t)stream, a);
+    SUNERF_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(pack_mlp_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, a);
   SUNERF_CHECK_LAUNCH();
   return 0;

@@ -412,6 +412,276 @@ struct Mlp {
   }
 };
 
+// ---- d <= 256: fp16 head product + two block-scaled fp8 correction products (format: sunerf_common.h, "fp8c") ----------
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pin_agpr8(v8i& f) { asm volatile("" : "+a"(f)); }
+
+// Stage C of a pair micro-op, fp8c operand format: the finished values go into fragment FP + (p >> 2) of the output set as
+// fp16 head (yhi) and as two fp8 words -- the head itself and the remainder scaled by 2^11 -- of the 64-deep fp8 operands
+// (group = fragment / 4; dword 2 (fragment % 4) + (p % 4) / 2, 16-bit word (p % 4) % 2).
+template <bool STASH>
+__device__ __forceinline__ void epi_stage_c8(const PairTmp& t, int p, int FP, half8* yhi, v8i* yh8, v8i* yl8, v8i& w8h,
+                                             v8i& w8l, half8& ch0, half8& ch1, Rsrc st, int st_off, int cos_delta) {
+  const int f = FP + (p >> 2), dq = p & 3;                 // literals after unrolling
+  yhi[f][2 * dq] = t.hi[0];
+  yhi[f][2 * dq + 1] = t.hi[1];
+  const int g = f >> 2, d = 2 * (f & 3) + (dq >> 1);
+  // the 64-deep fp8 operands of a group (4 fragments = 2 tiles) are collected in the VGPR tuples w8h / w8l and moved to
+  // the (AGPR-resident) operand set in one piece when the group is complete: partial writes to an 8-register AGPR tuple
+  // make the allocator copy the tuple around
+  if (dq & 1) {   // the word selector of the builtin must be a literal
+    w8h[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.s0, t.s1, w8h[d], true);
+    w8l[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.r0 * 2048.f, t.r1 * 2048.f, w8l[d], true);
+  } else {
+    w8h[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.s0, t.s1, 0, false);
+    w8l[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.r0 * 2048.f, t.r1 * 2048.f, 0, false);
+  }
+  if (STASH) {
+    if (p < 4) { ch0[2 * p] = t.cpk[0]; ch0[2 * p + 1] = t.cpk[1]; }
+    else { ch1[2 * p - 8] = t.cpk[0]; ch1[2 * p - 7] = t.cpk[1]; }
+  }
+  if (dq == 3) {                                            // fragment f is complete
+    pin_agpr(yhi[f]);
+    if ((f & 3) == 3) {
+      yh8[g] = w8h; yl8[g] = w8l;
+      pin_agpr8(yh8[g]); pin_agpr8(yl8[g]);
+    }
+    if (STASH) {
+      buf_store_nt(yhi[f], st, st_off + (p >> 2) * 1024);
+      buf_store_nt(p < 4 ? ch0 : ch1, st, st_off + (p >> 2) * 1024 + cos_delta);
+    }
+  }
+}
+
+template <int D>
+struct Mlp8 : Mlp<D> {
+  using M = Mlp<D>;
+  using M::KS; using M::NT; using M::PF; using M::PAGE_STEPS; using M::RING_STEPS; using M::RS_HIDDEN; using M::RS_IN;
+  using Pipe = typename M::Pipe;
+  static constexpr int G = KS / 4;                          // 64-deep groups per hidden tile (= per page: PAGE_STEPS == KS)
+  static constexpr int PIECES = Ring<D>::PIECES;
+  static_assert(PAGE_STEPS == KS && KS % 4 == 0, "fp8c: a hidden tile is one page of whole groups");
+
+  struct Pipe8 {            // A operands of the NEXT group to execute
+    half8 a16[4];
+    v8i al8, ah8;
+  };
+  struct Scales { int a_lo, a_hi; };   // E8M0 block scales of the two fp8 A operands of a layer: 127 - (sh + 11), 127 - sh
+
+  static __device__ __forceinline__ const char* group_ptr(const Pipe& p, int ring_step) { return p.frag + ring_step * 2048; }
+  static __device__ __forceinline__ v8i load8(const char* q) {
+    const v4i lo = *(const v4i*)q, hi = *(const v4i*)(q + 1024);
+    v8i r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+  }
+  // all operands of the group at ring position `ring_step` (a layer's first group: nothing prefetched it)
+  static __device__ __forceinline__ void preload(const Pipe& p, Pipe8& q, int ring_step) {
+    const char* b = group_ptr(p, ring_step);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q.a16[i] = *(const half8*)(b + i * 1024);
+    q.al8 = load8(b + 4096);
+    q.ah8 = load8(b + 6144);
+  }
+
+  // One hidden / out tile (KS k-steps = G groups = one page).  Per group six matrix instructions on one accumulator: four
+  // fp16 head products, then fp8(xh) * fp8(wl) and fp8(xl) * fp8(wh).  Each instruction's A operand is refilled with the
+  // next group's right behind it (in-place prefetch one group = 256+ matrix cycles ahead).  The previous tile's epilogue
+  // (8 pair micro-ops, writing fragments FP, FP + 1 of the y set) is dealt out over the first segments; it must be done
+  // before k-step KS - 2, whose operands it produces when the previous tile closed the layer above.
+  // RS0: ring k-step of the tile's first group (compile-time) or -1 (run-time, p.rstep).
+  template <bool HAS_PREV, int RS0, bool STASH>
+  static __device__ __forceinline__ f32x16 tile8(Ring<D>& ring, Pipe& p, Pipe8& q, f32x16 acc, const half8* xhi,
+                                                 const v8i* xh8, const v8i* xl8, const Scales sc, const f32x16& prev,
+                                                 int FP, half8* yhi, v8i* yh8, v8i* yl8, v8i& w8h, v8i& w8l, Rsrc st,
+                                                 int st_off, int cos_delta) {
+    constexpr int SEGS = 6 * ((KS - 2) / 4) + ((KS - 2) % 4);        // segments before the deadline
+    constexpr int PER = SEGS >= 16 ? 0 : (8 + SEGS - 1) / SEGS;      // 0: one micro-op per two segments (A+B | C)
+    half8 ch0, ch1;
+    PairTmp t[PER == 0 ? 1 : PER];
+    // the block-scaled fp8 instruction sums with ~17 bits (probe: 8e-6 relative on a 64-deep sum): harmless for the
+    // corrections themselves (2^-12 of the result) but not for a running sum of order one passed through it, so they
+    // get their own accumulator, added once per tile
+    f32x16 accc = {0};
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      // ring position (k-steps) of the next group's operands
+      int nrs;
+      if (RS0 >= 0) nrs = (RS0 + 4 * (g + 1)) % RING_STEPS;
+      else { nrs = p.rstep + 4 * (g + 1); nrs = nrs >= RING_STEPS ? nrs - RING_STEPS : nrs; }
+      const char* nb = group_ptr(p, nrs);
+      if (g == G - 1) {
+        // the refills below read the next page: acquire it (its successor's pieces, and in training the 4 stash stores of
+        // this tile's epilogue, may still be in flight)
+        ring.template acquire<(STASH && HAS_PREV) ? 4 : 0>();
+      }
+#pragma unroll
+      for (int sg = 0; sg < 6; ++sg) {
+        const int seg = 6 * g + sg;
+        if (sg < 4) {
+          acc = mfma16(q.a16[sg], xhi[4 * g + sg], acc);
+        } else if (sg == 4) {
+          accc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(q.al8, xh8[g], accc, 0, 0, 0, sc.a_lo, 0, 127);
+        } else {
+          accc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(q.ah8, xl8[g], accc, 0, 0, 0, sc.a_hi, 0, 127 - 11);
+        }
+        if (HAS_PREV) {
+          if (PER == 0) {
+            const int op = seg >> 1;
+            if (op < 8) {
+              if ((seg & 1) == 0) { epi_stage_a<STASH>(prev, op, t[0]); epi_stage_b<STASH>(t[0]); }
+              else epi_stage_c8<STASH>(t[0], op, FP, yhi, yh8, yl8, w8h, w8l, ch0, ch1, st, st_off, cos_delta);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < PER; ++e) {
+              const int op = seg * PER + e;
+              if (op < 8) {
+                epi_stage_a<STASH>(prev, op, t[e]);
+                epi_stage_b<STASH>(t[e]);
+                epi_stage_c8<STASH>(t[e], op, FP, yhi, yh8, yl8, w8h, w8l, ch0, ch1, st, st_off, cos_delta);
+              }
+            }
+          }
+        }
+        // weight stream: two pieces per group behind the acquire (page + 3 into the slot everyone left)
+        if (sg == 1 || sg == 3) {
+          const int piece = 2 * ((g + 1) % G) + (sg == 3 ? 1 : 0);
+          if (piece < PIECES) M::issue_piece_dyn(ring, piece);
+        }
+        // in-place prefetch of the next group's operand
+        if (sg < 4) q.a16[sg] = *(const half8*)(nb + sg * 1024);
+        else if (sg == 4) q.al8 = load8(nb + 4096);
+        else q.ah8 = load8(nb + 6144);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (RS0 < 0) {
+      p.rstep += KS;
+      if (p.rstep >= RING_STEPS) p.rstep -= RING_STEPS;
+    }
+    return acc + accc;
+  }
+
+  // in-layer tile (6 k-steps, classic hi | lo weights and encoding operands) with the fp8c epilogue format
+  template <int T0, bool HAS_PREV, int RS0, bool STASH>
+  static __device__ __forceinline__ f32x16 tile_in(Ring<D>& ring, Pipe& p, f32x16 acc, const half8* xhi, const half8* xlo,
+                                                   const f32x16& prev, int FP, half8* yhi, v8i* yh8, v8i* yl8, v8i& w8h,
+                                                   v8i& w8l, Rsrc st, int st_off, int cos_delta) {
+    constexpr int KIN = SUNERF_KS0;
+    constexpr int EPI_STEPS = KIN - 2, PER = (8 + EPI_STEPS - 1) / EPI_STEPS;
+    constexpr int ACQ = (PAGE_STEPS - PF) % PAGE_STEPS;
+    half8 ch0, ch1;
+#pragma unroll
+    for (int s = 0; s < KIN; ++s) {
+      const int r = (T0 + s) % PF;
+      PairTmp t[PER];
+      acc = mfma16(p.alo[r], xhi[s], acc);
+      if (HAS_PREV) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e)
+          if (s * PER + e < 8) epi_stage_a<STASH>(prev, s * PER + e, t[e]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc = mfma16(p.ahi[r], xlo[s], acc);
+      if (HAS_PREV) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e)
+          if (s * PER + e < 8) epi_stage_b<STASH>(t[e]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc = mfma16(p.ahi[r], xhi[s], acc);
+      if (HAS_PREV) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e)
+          if (s * PER + e < 8) epi_stage_c8<STASH>(t[e], s * PER + e, FP, yhi, yh8, yl8, w8h, w8l, ch0, ch1, st, st_off, cos_delta);
+      }
+      {
+        const int phase = (T0 + s) % PAGE_STEPS;
+        if (phase == ACQ) ring.template acquire<0>();
+        const int rel = (phase - ACQ - 1 + PAGE_STEPS) % PAGE_STEPS;
+        if (rel % 2 == 0 && rel / 2 < PIECES) M::issue_piece_dyn(ring, rel / 2);
+      }
+      if (RS0 >= 0) {
+        M::load_frag(p, r, (RS0 + s + PF) % RING_STEPS);
+      } else {
+        int rs = p.rstep + s + PF;
+        rs = rs >= RING_STEPS ? rs - RING_STEPS : rs;
+        M::load_frag(p, r, rs);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (RS0 < 0) {
+      p.rstep += KIN;
+      if (p.rstep >= RING_STEPS) p.rstep -= RING_STEPS;
+    }
+    return acc;
+  }
+
+  // in layer: encoding (6 k-steps, hi | lo) -> y set (fp8c format); returns the last tile's accumulator (its epilogue is
+  // carried into the first hidden tile)
+  template <bool STASH>
+  static __device__ __forceinline__ f32x16 in_layer(Ring<D>& ring, Pipe& p, const float* bias, int h, const half8* ehi,
+                                                    const half8* elo, half8* yhi, v8i* yh8, v8i* yl8, v8i& w8h, v8i& w8l,
+                                                    Rsrc st, int st_own) {
+    f32x16 prev = {0};
+    constexpr int CD = KS * 1024;
+#pragma unroll
+    for (int U = 0; U < NT; ++U) {
+      f32x16 acc = bias_tile(bias + 32 * U, h);
+#define SUNERF_TILE_IN(UU)                                                                                           \
+      if (U == UU) {                                                                                                   \
+        constexpr int RS = RS_IN < 0 ? -1 : (RS_IN + UU * SUNERF_KS0) % RING_STEPS;                                    \
+        constexpr int T0 = (UU * SUNERF_KS0) % PAGE_STEPS;                                                             \
+        acc = tile_in<T0, (UU > 0), RS, STASH>(ring, p, acc, ehi, elo, prev, 2 * UU - 2, yhi, yh8, yl8, w8h, w8l, st,  \
+                                               st_own + (2 * UU - 2) * 1024, CD);                                     \
+      }
+      SUNERF_TILE_IN(0) SUNERF_TILE_IN(1) SUNERF_TILE_IN(2) SUNERF_TILE_IN(3)
+      SUNERF_TILE_IN(4) SUNERF_TILE_IN(5) SUNERF_TILE_IN(6) SUNERF_TILE_IN(7)
+#undef SUNERF_TILE_IN
+      prev = acc;
+    }
+    return prev;
+  }
+
+  // hidden layer: x set -> y set; `carry` = accumulator of the layer above's last tile (its epilogue completes x while our
+  // first tile runs: fragments 2 NT - 2, 2 NT - 1 = k-steps KS - 2, KS - 1)
+  template <bool STASH>
+  static __device__ __forceinline__ f32x16 hidden_layer(Ring<D>& ring, Pipe& p, Pipe8& q, const float* bias, int h,
+                                                        const Scales sc, half8* xhi, v8i* xh8, v8i* xl8, half8* yhi,
+                                                        v8i* yh8, v8i* yl8, v8i& w8h, v8i& w8l, const f32x16& carry, Rsrc st,
+                                                        int st_prev, int st_own) {
+    f32x16 prev = carry;
+    constexpr int CD = KS * 1024;
+    constexpr int XL = 2 * NT - 2;
+#pragma unroll
+    for (int U = 0; U < NT; ++U) {
+      f32x16 acc = bias_tile(bias + 32 * U, h);
+#define SUNERF_TILE8(UU)                                                                                             \
+      if (U == UU) {                                                                                                   \
+        constexpr int RS = RS_HIDDEN < 0 ? -1 : (RS_HIDDEN + UU * KS) % RING_STEPS;                                    \
+        if (UU == 0) acc = tile8<true, RS, STASH>(ring, p, q, acc, xhi, xh8, xl8, sc, prev, XL, xhi, xh8, xl8, w8h, w8l, st, \
+                                                  st_prev + XL * 1024, CD);                                           \
+        else acc = tile8<true, RS, STASH>(ring, p, q, acc, xhi, xh8, xl8, sc, prev, 2 * UU - 2, yhi, yh8, yl8, w8h, w8l, st, \
+                                          st_own + (2 * UU - 2) * 1024, CD);                                          \
+      }
+      SUNERF_TILE8(0) SUNERF_TILE8(1) SUNERF_TILE8(2) SUNERF_TILE8(3) SUNERF_TILE8(4) SUNERF_TILE8(5) SUNERF_TILE8(6) SUNERF_TILE8(7)
+#undef SUNERF_TILE8
+      prev = acc;
+    }
+    return prev;
+  }
+
+  template <bool STASH>
+  static __device__ __forceinline__ f32x16 out_layer(Ring<D>& ring, Pipe& p, Pipe8& q, const float* bias, int h,
+                                                     const Scales sc, half8* xhi, v8i* xh8, v8i* xl8, v8i& w8h, v8i& w8l,
+                                                     const f32x16& carry, Rsrc st, int st_prev) {
+    constexpr int XL = 2 * NT - 2;
+    return tile8<true, RS_HIDDEN, STASH>(ring, p, q, bias_tile(bias, h), xhi, xh8, xl8, sc, carry, XL, xhi, xh8, xl8, w8h, w8l,
+                                         st, st_prev + XL * 1024, KS * 1024);
+  }
+};
+
 template <int D, bool STASH>
 __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
   using M = Mlp<D>;
@@ -470,39 +740,55 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
       f32x16 out;
       const float* obias = bias + (size_t)(a.n_linear - 1) * D;
       if constexpr (!M::SPILL) {
-        half8 xa_hi[M::XK], xa_lo[M::XK], xb_hi[M::XK], xb_lo[M::XK];
-        {  // positional encoding straight into the in-layer B fragments (k-steps 0..5 of xb)
-          encode_point(v, h, [&](int q, float val) {
-            const _Float16 hi = (_Float16)val;
-            xb_hi[q >> 3][q & 7] = hi;
-            xb_lo[q >> 3][q & 7] = (_Float16)(val - (float)hi);
-          });
-#pragma unroll
-          for (int s = 0; s < SUNERF_KS0; ++s) { pin_agpr(xb_hi[s]); pin_agpr(xb_lo[s]); }
-        }
+        using M8 = Mlp8<D>;
+        constexpr int G = M8::G;
+        // two operand sets in the fp8c format: fp16 heads + the two 64-deep fp8 operands (head, scaled remainder)
+        half8 xa_hi[M::KS], xb_hi[M::KS];
+        v8i xa_h8[G], xa_l8[G], xb_h8[G], xb_l8[G];
+        half8 e_hi[SUNERF_KS0], e_lo[SUNERF_KS0];            // encoding, classic hi | lo operands of the in layer
+        encode_point(v, h, [&](int q, float val) {
+          const _Float16 hi = (_Float16)val;
+          e_hi[q >> 3][q & 7] = hi;
+          e_lo[q >> 3][q & 7] = (_Float16)(val - (float)hi);
+        });
         if (STASH) {
 #pragma unroll
-          for (int s = 0; s < SUNERF_KS0; ++s) buf_store(xb_hi[s], st, s * 1024);
+          for (int s = 0; s < SUNERF_KS0; ++s) buf_store(e_hi[s], st, s * 1024);
         }
-        // in layer: 84(96) -> D
-        f32x16 carry = {0};
-        const Rsrc none = make_rsrc(nullptr, 0);
-        carry = M::template layer<SUNERF_KS0, false, M::RS_IN, STASH>(ring, pipe, bias, h, xb_hi, xb_lo, xa_hi, xa_lo, carry,
-                                                                      st, 0, (int)SL.h_off(0), none);
-        // hidden layers, ping-pong between the two register sets
+        const int* shp = (const int*)(a.packed + L.scale_off());
+        // the in layer's first k-steps: nothing prefetched them (the previous chunk ended with an fp8c tile)
+        if (c != 0 || group != (int64_t)blockIdx.x) {
+#pragma unroll
+          for (int s = 0; s < M::PF; ++s) {
+            int rs = M::RS_IN >= 0 ? (M::RS_IN + s) % M::RING_STEPS : pipe.rstep + s;
+            if (M::RS_IN < 0 && rs >= M::RING_STEPS) rs -= M::RING_STEPS;
+            M::load_frag(pipe, s, rs);
+          }
+        }
+        v8i w8h, w8l;                                          // fp8 operands of the group under construction
+        f32x16 carry = M8::template in_layer<STASH>(ring, pipe, bias, h, e_hi, e_lo, xa_hi, xa_h8, xa_l8, w8h, w8l, st, (int)SL.h_off(0));
+        typename M8::Pipe8 q8;
+        M8::preload(pipe, q8, M::RS_HIDDEN >= 0 ? M::RS_HIDDEN : pipe.rstep);
+        auto scales = [&](int l) {
+          const int sh = shp[l];
+          typename M8::Scales sc = {127 - (sh + 11), 127 - sh};
+          return sc;
+        };
         int l = 1;
         for (; l + 1 < a.n_linear - 1; l += 2) {
-          carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)l * D, h, xa_hi, xa_lo, xb_hi, xb_lo,
-                                                                      carry, st, (int)SL.h_off(l - 1), (int)SL.h_off(l), none);
-          carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)(l + 1) * D, h, xb_hi, xb_lo, xa_hi,
-                                                                      xa_lo, carry, st, (int)SL.h_off(l), (int)SL.h_off(l + 1), none);
+          carry = M8::template hidden_layer<STASH>(ring, pipe, q8, bias + (size_t)l * D, h, scales(l), xa_hi, xa_h8, xa_l8, xb_hi,
+                                                   xb_h8, xb_l8, w8h, w8l, carry, st, (int)SL.h_off(l - 1), (int)SL.h_off(l));
+          carry = M8::template hidden_layer<STASH>(ring, pipe, q8, bias + (size_t)(l + 1) * D, h, scales(l + 1), xb_hi, xb_h8,
+                                                   xb_l8, xa_hi, xa_h8, xa_l8, w8h, w8l, carry, st, (int)SL.h_off(l), (int)SL.h_off(l + 1));
         }
         if (l < a.n_linear - 1) {
-          carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)l * D, h, xa_hi, xa_lo, xb_hi, xb_lo,
-                                                                      carry, st, (int)SL.h_off(l - 1), (int)SL.h_off(l), none);
-          out = M::template out_layer<STASH>(ring, pipe, obias, h, xb_hi, xb_lo, carry, st, (int)SL.h_off(l), none);
+          carry = M8::template hidden_layer<STASH>(ring, pipe, q8, bias + (size_t)l * D, h, scales(l), xa_hi, xa_h8, xa_l8, xb_hi,
+                                                   xb_h8, xb_l8, w8h, w8l, carry, st, (int)SL.h_off(l - 1), (int)SL.h_off(l));
+          out = M8::template out_layer<STASH>(ring, pipe, q8, obias, h, scales(a.n_linear - 1), xb_hi, xb_h8, xb_l8, w8h, w8l, carry, st,
+                                              (int)SL.h_off(l));
         } else {
-          out = M::template out_layer<STASH>(ring, pipe, obias, h, xa_hi, xa_lo, carry, st, (int)SL.h_off(l - 1), none);
+          out = M8::template out_layer<STASH>(ring, pipe, q8, obias, h, scales(a.n_linear - 1), xa_hi, xa_h8, xa_l8, w8h, w8l, carry, st,
+                                              (int)SL.h_off(l - 1));
         }
       } else {
         // d_filter = 512: ONE activation set in registers (256 AGPRs); every layer writes its output fragments to this

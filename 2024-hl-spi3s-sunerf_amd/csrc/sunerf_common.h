@@ -64,8 +64,27 @@ struct PackedLayout {
   __host__ __device__ size_t stream_bytes() const { return pass_bytes(); }   // always a multiple of the page size
   __host__ __device__ size_t bias_off() const { return stream_bytes(); }
   __host__ __device__ size_t n_bias() const { return (size_t)(n_linear - 1) * D + 32; }
-  __host__ __device__ size_t total_bytes() const { return bias_off() + n_bias() * 4; }
+  // d <= 256 ("fp8c" stream format, below): per-layer scale exponents sh[l] (int[16]) and the max |w| they derive from
+  // (float bit patterns, uint[16]; scratch of the pack kernels)
+  __host__ __device__ static constexpr bool fp8c(int d) { return d <= 256; }
+  __host__ __device__ size_t scale_off() const { return bias_off() + n_bias() * 4; }
+  __host__ __device__ size_t absmax_off() const { return scale_off() + 64; }
+  __host__ __device__ size_t total_bytes() const { return absmax_off() + 64; }
 };
+
+// "fp8c" stream format of the hidden and out layers (d <= 256).  A product x*w with x = xh + xl, w = wh + wl (fp16 heads,
+// exact fp32 remainders) is formed as  xh*wh  [v_mfma_f32_32x32x16_f16]  +  fp8(xh)*fp8(wl)  +  fp8(xl)*fp8(wh)
+// [v_mfma_scale_f32_32x32x64_f8f6f4, e4m3, block scales]: the two correction terms are 2^-12 of the product, so their fp8
+// rounding (2^-4) is a 2^-16 relative error (measured 1.3e-6 on the output of an 8 x 256 net) -- and one 64-deep fp8
+// instruction replaces four 16-deep fp16 ones at twice the rate.  Per 64 input features ("group" = 4 k-steps) the stream
+// holds 8 KiB:
+//   [4 x 1 KiB : wh fragments of the 4 k-steps, as in the classic format]
+//   [2 x 1 KiB : fp8(wl * 2^(sh+11)), lane l = 16 bytes per KiB; byte j = 8 sl + e of the lane's 32 <-> k-step 4g + sl,
+//                element e (same feature order as the fp16 fragments); first KiB = bytes 0..15, second = bytes 16..31]
+//   [2 x 1 KiB : fp8(wh * 2^sh), same arrangement]
+// with sh = 8 - ceil(log2 max|w|) per layer (|wh 2^sh| < 256, |wl 2^(sh+11)| <= 128; e4m3 saturates at 448).  The in
+// layer (96 = 6 k-steps, not a multiple of 4) keeps the classic hi | lo format.
+constexpr int SUNERF_GROUP_BYTES = 8192;
 
 // Activation stash written by the training forward pass and read by the backward kernels.  Everything is kept in
 // MFMA B-fragment order (1 KiB per fragment: lane l = 16 bytes = 8 fp16 at offset 16 l; element e of lane half h of

@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol(lib):
 def test_size_helpers(lib):
     # packed image: in layer 8 tiles x 6 k-steps, 7 hidden layers x 8 tiles x 16 k-steps, out 16 k-steps, 2 KiB each
     steps = 8 * 6 + 7 * 8 * 16 + 16
-    assert lib.sunerf_packed_mlp_bytes(256, 9) == steps * 2048 + (8 * 256 + 32) * 4
+    # + biases + 16 per-layer scale exponents + 16 max|w| scratch words (fp8c stream format)
+    assert lib.sunerf_packed_mlp_bytes(256, 9) == steps * 2048 + (8 * 256 + 32) * 4 + 128
     assert lib.sunerf_packed_mlp_bytes(250, 9) == 0 and lib.sunerf_packed_mlp_bytes(256, 1) == 0
     assert lib.sunerf_packed_mlp_t_bytes(256, 9) == 8 * 1024 + 7 * 8 * 16 * 2048     # out^T hi only; hidden hi + lo
     # stash: (6 enc + 8 layers x 2 x 16) fragments of 1 KiB per 32-sample chunk, + 1 spare chunk
