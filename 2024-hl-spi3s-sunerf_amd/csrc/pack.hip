@@ -8,6 +8,7 @@ struct PackArgs {
   const float* W[SUNERF_MAX_LAYERS];
   const float* b[SUNERF_MAX_LAYERS];
   int n_linear, D, d_out;
+  int fp8c;          // hidden / out layers in the fp8c stream format (SUNERF_PRECISION_FAST)
   char* packed;
 };
 
@@ -82,7 +83,7 @@ __global__ void pack_mlp_kernel(PackArgs a) {
   if (col >= 0 && row < n_rows) w = a.W[l][(size_t)row * in_dim + col];
   if (l < a.n_linear - 1) w *= 0.15915494309189535f;   // pre-activation in revolutions for v_sin_f32
   const _Float16 hi = (_Float16)w;                  // round to nearest
-  if (l >= 1 && PackedLayout::fp8c(a.D)) {          // fp8c format (sunerf_common.h)
+  if (l >= 1 && a.fp8c) {                           // fp8c format (sunerf_common.h)
     const int sh = scale_exponent(((const unsigned*)(a.packed + L.absmax_off()))[l]);
     if (U == 0 && s == 0 && lane == 0 && e == 0) ((int*)(a.packed + L.scale_off()))[l] = sh;
     char* grp = a.packed + L.block_off(l, U) + (size_t)(s >> 2) * SUNERF_GROUP_BYTES;
@@ -107,7 +108,7 @@ extern "C" size_t sunerf_packed_mlp_bytes(int d_filter, int n_linear) {
 }
 
 extern "C" int sunerf_pack_mlp(const float* const* weights_host, const float* const* biases_host, int n_linear,
-                               int d_filter, int d_out, void* packed, void* stream) {
+                               int d_filter, int d_out, int precision, void* packed, void* stream) {
   if (!weights_host || !biases_host || !packed) return SUNERF_E_BADARG;
   if (d_filter <= 0 || d_filter % 32 || n_linear < 2 || n_linear > SUNERF_MAX_LAYERS || d_out < 1 || d_out > 32)
     return SUNERF_E_UNSUPPORTED;
@@ -117,14 +118,17 @@ extern "C" int sunerf_pack_mlp(const float* const* weights_host, const float* co
     a.W[i] = weights_host[i];
     a.b[i] = biases_host[i];
   }
+  if (precision != SUNERF_PRECISION_FAST && precision != SUNERF_PRECISION_EXACT) return SUNERF_E_BADARG;
+  if (precision == SUNERF_PRECISION_FAST && d_filter > 256) return SUNERF_E_UNSUPPORTED;
   a.n_linear = n_linear; a.D = d_filter; a.d_out = d_out; a.packed = (char*)packed;
+  a.fp8c = precision == SUNERF_PRECISION_FAST;
   const PackedLayout L(d_filter, n_linear);
   const size_t total = (size_t)L.NT * SUNERF_KS0 * 512 + (size_t)(n_linear - 2) * L.NT * L.KS * 512 +
                        (size_t)L.KS * 512 + L.n_bias();
   const int threads = 256;
   const unsigned blocks = (unsigned)((total + threads - 1) / threads);
   SUNERF_CLEAR_ERROR();
-  if (PackedLayout::fp8c(d_filter)) {
+  if (a.fp8c) {
     hipError_t e = hipMemsetAsync(a.packed + L.scale_off(), 0, 128, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pack_absmax_kernel, dim3(64, n_linear - 1), dim3(256), 0, (hipStream_t)stream, a);

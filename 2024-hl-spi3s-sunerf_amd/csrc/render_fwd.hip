@@ -682,7 +682,7 @@ struct Mlp8 : Mlp<D> {
   }
 };
 
-template <int D, bool STASH>
+template <int D, bool STASH, bool FP8C>
 __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
   using M = Mlp<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
       }
       f32x16 out;
       const float* obias = bias + (size_t)(a.n_linear - 1) * D;
-      if constexpr (!M::SPILL) {
+      if constexpr (FP8C) {
         using M8 = Mlp8<D>;
         constexpr int G = M8::G;
         // two operand sets in the fp8c format: fp16 heads + the two 64-deep fp8 operands (head, scaled remainder)
@@ -789,6 +789,41 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
         } else {
           out = M8::template out_layer<STASH>(ring, pipe, q8, obias, h, scales(a.n_linear - 1), xa_hi, xa_h8, xa_l8, w8h, w8l, carry, st,
                                               (int)SL.h_off(l - 1));
+        }
+      } else if constexpr (!M::SPILL) {   // exact mode: three fp16 products per term (hi*hi + hi*lo + lo*hi)
+        half8 xa_hi[M::XK], xa_lo[M::XK], xb_hi[M::XK], xb_lo[M::XK];
+        {  // positional encoding straight into the in-layer B fragments (k-steps 0..5 of xb)
+          encode_point(v, h, [&](int q, float val) {
+            const _Float16 hi = (_Float16)val;
+            xb_hi[q >> 3][q & 7] = hi;
+            xb_lo[q >> 3][q & 7] = (_Float16)(val - (float)hi);
+          });
+#pragma unroll
+          for (int s = 0; s < SUNERF_KS0; ++s) { pin_agpr(xb_hi[s]); pin_agpr(xb_lo[s]); }
+        }
+        if (STASH) {
+#pragma unroll
+          for (int s = 0; s < SUNERF_KS0; ++s) buf_store(xb_hi[s], st, s * 1024);
+        }
+        // in layer: 84(96) -> D
+        f32x16 carry = {0};
+        const Rsrc none = make_rsrc(nullptr, 0);
+        carry = M::template layer<SUNERF_KS0, false, M::RS_IN, STASH>(ring, pipe, bias, h, xb_hi, xb_lo, xa_hi, xa_lo, carry,
+                                                                      st, 0, (int)SL.h_off(0), none);
+        // hidden layers, ping-pong between the two register sets
+        int l = 1;
+        for (; l + 1 < a.n_linear - 1; l += 2) {
+          carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)l * D, h, xa_hi, xa_lo, xb_hi, xb_lo,
+                                                                      carry, st, (int)SL.h_off(l - 1), (int)SL.h_off(l), none);
+          carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)(l + 1) * D, h, xb_hi, xb_lo, xa_hi,
+                                                                      xa_lo, carry, st, (int)SL.h_off(l), (int)SL.h_off(l + 1), none);
+        }
+        if (l < a.n_linear - 1) {
+          carry = M::template layer<M::KS, true, M::RS_HIDDEN, STASH>(ring, pipe, bias + (size_t)l * D, h, xa_hi, xa_lo, xb_hi, xb_lo,
+                                                                      carry, st, (int)SL.h_off(l - 1), (int)SL.h_off(l), none);
+          out = M::template out_layer<STASH>(ring, pipe, obias, h, xb_hi, xb_lo, carry, st, (int)SL.h_off(l), none);
+        } else {
+          out = M::template out_layer<STASH>(ring, pipe, obias, h, xa_hi, xa_lo, carry, st, (int)SL.h_off(l - 1), none);
         }
       } else {
         // d_filter = 512: ONE activation set in registers (256 AGPRs); every layer writes its output fragments to this
@@ -886,12 +921,12 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two prefetches still in flight target our LDS: drain
 }
 
-template <int D, bool STASH>
+template <int D, bool STASH, bool FP8C>
 int launch_render_t(const RenderArgs& a, hipStream_t stream) {
   const PackedLayout L(D, a.n_linear);
   const size_t lds = (size_t)Ring<D>::RING + L.n_bias() * 4;
   if (lds > 160 * 1024) return SUNERF_E_UNSUPPORTED;
-  hipError_t e = hipFuncSetAttribute((const void*)render_fwd_kernel<D, STASH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute((const void*)render_fwd_kernel<D, STASH, FP8C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   const int64_t n_groups = (a.n_rays + WAVES - 1) / WAVES;
   int dev = 0, cus = 256;
@@ -900,13 +935,17 @@ int launch_render_t(const RenderArgs& a, hipStream_t stream) {
   if (cus > 1024) cus = 1024;   // sunerf_render_workspace_bytes is sized for at most 1024 workgroups
   const unsigned grid = (unsigned)(n_groups < cus ? n_groups : cus);
   SUNERF_CLEAR_ERROR();
-  hipLaunchKernelGGL((render_fwd_kernel<D, STASH>), dim3(grid), dim3(THREADS), lds, stream, a);
+  hipLaunchKernelGGL((render_fwd_kernel<D, STASH, FP8C>), dim3(grid), dim3(THREADS), lds, stream, a);
   SUNERF_CHECK_LAUNCH();
   return 0;
 }
 template <int D>
-int launch_render(const RenderArgs& a, hipStream_t stream) {
-  return a.stash ? launch_render_t<D, true>(a, stream) : launch_render_t<D, false>(a, stream);
+int launch_render(const RenderArgs& a, int precision, hipStream_t stream) {
+  if constexpr (D <= 256) {
+    if (precision == SUNERF_PRECISION_FAST)
+      return a.stash ? launch_render_t<D, true, true>(a, stream) : launch_render_t<D, false, true>(a, stream);
+  }
+  return a.stash ? launch_render_t<D, true, false>(a, stream) : launch_render_t<D, false, false>(a, stream);
 }
 
 }  // namespace
@@ -923,7 +962,7 @@ extern "C" size_t sunerf_act_stash_bytes(int64_t n_rays, int n_samples, int d_fi
   return (size_t)chunks * StashLayout(d_filter, n_linear).chunk_bytes();
 }
 
-extern "C" int sunerf_emission_render_fwd(const void* packed, int d_filter, int n_linear, const float* rays_o,
+extern "C" int sunerf_emission_render_fwd(const void* packed, int d_filter, int n_linear, int precision, const float* rays_o,
                                           const float* rays_d, const float* times, const float* z_vals,
                                           int64_t n_rays, int n_samples, float* image, float* weights,
                                           float* absorption, float* raw, float* height_map, float* absorption_map,
@@ -931,6 +970,8 @@ extern "C" int sunerf_emission_render_fwd(const void* packed, int d_filter, int 
                                           size_t workspace_bytes, void* stream) {
   if (n_rays < 0 || n_samples < 2) return SUNERF_E_BADARG;
   if (n_linear < 2 || n_linear > SUNERF_MAX_LAYERS) return SUNERF_E_UNSUPPORTED;
+  if (precision != SUNERF_PRECISION_FAST && precision != SUNERF_PRECISION_EXACT) return SUNERF_E_BADARG;
+  if (precision == SUNERF_PRECISION_FAST && d_filter > 256) return SUNERF_E_UNSUPPORTED;   // packed images differ
   if (n_rays == 0) return 0;      // an empty batch is valid (its tensors have null data pointers)
   if (!packed || !rays_o || !rays_d || !times || !z_vals || !image || !weights || !absorption) return SUNERF_E_BADARG;
   RenderArgs a;
@@ -941,10 +982,10 @@ extern "C" int sunerf_emission_render_fwd(const void* packed, int d_filter, int 
   a.scratch = (char*)workspace;
   if (workspace_bytes < sunerf_render_workspace_bytes(d_filter)) return SUNERF_E_WORKSPACE;
   switch (d_filter) {
-    case 64: return launch_render<64>(a, (hipStream_t)stream);
-    case 128: return launch_render<128>(a, (hipStream_t)stream);
-    case 256: return launch_render<256>(a, (hipStream_t)stream);
-    case 512: return launch_render<512>(a, (hipStream_t)stream);
+    case 64: return launch_render<64>(a, precision, (hipStream_t)stream);
+    case 128: return launch_render<128>(a, precision, (hipStream_t)stream);
+    case 256: return launch_render<256>(a, precision, (hipStream_t)stream);
+    case 512: return launch_render<512>(a, precision, (hipStream_t)stream);
     default: return SUNERF_E_UNSUPPORTED;
   }
 }

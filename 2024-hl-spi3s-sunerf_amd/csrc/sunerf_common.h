@@ -64,9 +64,8 @@ struct PackedLayout {
   __host__ __device__ size_t stream_bytes() const { return pass_bytes(); }   // always a multiple of the page size
   __host__ __device__ size_t bias_off() const { return stream_bytes(); }
   __host__ __device__ size_t n_bias() const { return (size_t)(n_linear - 1) * D + 32; }
-  // d <= 256 ("fp8c" stream format, below): per-layer scale exponents sh[l] (int[16]) and the max |w| they derive from
+  // "fp8c" stream format (below; d <= 256, SUNERF_PRECISION_FAST): per-layer scale exponents sh[l] (int[16]) and the max |w| they derive from
   // (float bit patterns, uint[16]; scratch of the pack kernels)
-  __host__ __device__ static constexpr bool fp8c(int d) { return d <= 256; }
   __host__ __device__ size_t scale_off() const { return bias_off() + n_bias() * 4; }
   __host__ __device__ size_t absmax_off() const { return scale_off() + 64; }
   __host__ __device__ size_t total_bytes() const { return absmax_off() + 64; }

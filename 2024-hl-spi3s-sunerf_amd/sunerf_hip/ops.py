@@ -14,6 +14,17 @@ SAMPLER_STRATIFIED = 0
 SAMPLER_SPHERICAL = 1
 SUPPORTED_D_FILTER = (64, 128, 256, 512)
 TRAINABLE_D_FILTER = (64, 128, 256, 512)
+PRECISION_FAST, PRECISION_EXACT = 0, 1     # include/sunerf_hip.h: SUNERF_PRECISION_*
+
+
+def default_precision(d_filter: int) -> int:
+    """Forward arithmetic of newly packed models: ``SUNERF_FORWARD_PRECISION=exact`` (environment) selects three fp16
+    products per term everywhere; the default is the fp16 + fp8-correction mode where it exists (d_filter <= 256)."""
+    import os
+    if d_filter > 256 or os.environ.get('SUNERF_FORWARD_PRECISION', 'fast').lower() == 'exact':
+        return PRECISION_EXACT
+    return PRECISION_FAST
+
 _workspaces = {}                        # device -> scratch for the d_filter = 512 render kernel (per stream use is serial)
 
 
@@ -42,9 +53,12 @@ class PackedMLP:
     """fp16 hi/lo A-fragment image of one NeRF MLP (see csrc/sunerf_common.h).  Re-pack after every
     parameter update (``repack``)."""
 
-    def __init__(self, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]):
+    def __init__(self, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], precision: Optional[int] = None):
         self.n_linear = len(weights)
         self.d_filter = int(weights[0].shape[0])
+        self.precision = default_precision(self.d_filter) if precision is None else int(precision)
+        if self.precision == PRECISION_FAST and self.d_filter > 256:
+            raise ValueError('the fp8-correction forward exists for d_filter <= 256 only')
         self.d_out = int(weights[-1].shape[0])
         if self.d_filter not in SUPPORTED_D_FILTER:
             raise ValueError(f'd_filter={self.d_filter} is not in the compiled set {SUPPORTED_D_FILTER}')
@@ -71,7 +85,7 @@ class PackedMLP:
             bs.append(_dev(b.detach(), f'bias[{i}]', (d_o,)))
         W = (ctypes.c_void_p * self.n_linear)(*[w.data_ptr() for w in ws])
         B = (ctypes.c_void_p * self.n_linear)(*[b.data_ptr() for b in bs])
-        st = lib.sunerf_pack_mlp(W, B, self.n_linear, self.d_filter, self.d_out, _ptr(self.buffer),
+        st = lib.sunerf_pack_mlp(W, B, self.n_linear, self.d_filter, self.d_out, self.precision, _ptr(self.buffer),
                                  _stream(self.device))
         _l.check(st, 'sunerf_pack_mlp')
         self._keepalive = (ws, bs)   # until the pack kernel has run on the stream
@@ -146,7 +160,7 @@ def emission_render_fwd(packed: PackedMLP, rays_o, rays_d, times, z_vals, reg_ra
     hm = am = reg = None
     if want_epilogues:
         hm, am, reg = torch.empty(n, **f32), torch.empty(n, **f32), torch.empty(n, s, **f32)
-    st = lib.sunerf_emission_render_fwd(_ptr(packed.buffer), packed.d_filter, packed.n_linear, _ptr(rays_o),
+    st = lib.sunerf_emission_render_fwd(_ptr(packed.buffer), packed.d_filter, packed.n_linear, packed.precision, _ptr(rays_o),
                                         _ptr(rays_d), _ptr(times), _ptr(z_vals), n, s, _ptr(out['image']),
                                         _ptr(out['weights']), _ptr(out['absorption']), _ptr(raw), _ptr(hm), _ptr(am),
                                         _ptr(reg), float(reg_radius), _ptr(stash), _ptr(ws), ws_bytes, _stream(dev))

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUNERF_ABI_VERSION 1
+#define SUNERF_ABI_VERSION 2
 
 #define SUNERF_E_BADARG   (-1)   /* null pointer / non-positive size                               */
 #define SUNERF_E_UNSUPPORTED (-2) /* d_filter / n_layers / sample count outside the compiled set     */
@@ -35,6 +35,15 @@ extern "C" {
 
 #define SUNERF_MAX_LAYERS 16     /* Linear layers per MLP including in_layer and out_layer          */
 #define SUNERF_ENC_DIM    84     /* PositionalEncoding(d_input=4, n_freqs=10).d_output, model.py:109 */
+
+/* forward arithmetic of the MLP products x*w (x, w split into fp16 head + exact fp32 remainder); the packed image and the
+ * render call must name the same mode.
+ *   FAST  (d_filter <= 256): head*head on the fp16 matrix cores + the two cross terms as block-scaled fp8 products
+ *         (v_mfma_scale_f32_32x32x64_f8f6f4); raw MLP output within ~1e-5 abs of fp32 (images ~1e-5 rel: the 1e-4 parity
+ *         gate with a decade to spare), 18 % faster than EXACT at d_filter = 256
+ *   EXACT : all three terms as fp16 products (fp32-class results, raw within ~1e-7); the only mode at d_filter = 512 */
+#define SUNERF_PRECISION_FAST  0
+#define SUNERF_PRECISION_EXACT 1
 
 /* sampler kinds -- sunerf/train/sampling.py */
 #define SUNERF_SAMPLER_STRATIFIED 0   /* StratifiedSampler.forward  sampling.py:68-102 */
@@ -52,11 +61,12 @@ int sunerf_abi_version(void);
  *   biases_host[i]  -> device fp32 b_i [out_i]
  *   n_linear = n_layers + 1 : in_layer (84 -> d_filter), n_layers-1 hidden (d_filter -> d_filter), out_layer
  *   packed: device buffer of sunerf_packed_mlp_bytes() bytes, 16-byte aligned
+ *   precision: SUNERF_PRECISION_FAST / _EXACT (above); selects the stream format of the hidden and out layers
  * ---------------------------------------------------------------------------------------------------------- */
 size_t sunerf_packed_mlp_bytes(int d_filter, int n_linear);
 
 int sunerf_pack_mlp(const float* const* weights_host, const float* const* biases_host, int n_linear,
-                    int d_filter, int d_out, void* packed, void* stream);
+                    int d_filter, int d_out, int precision, void* packed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Sample placement along rays.
@@ -94,7 +104,7 @@ size_t sunerf_act_stash_bytes(int64_t n_rays, int n_samples, int d_filter, int n
 /* d_filter = 512 (the reference's default width, model.py:16): scratch for layer outputs; 0 for narrower nets */
 size_t sunerf_render_workspace_bytes(int d_filter);
 
-int sunerf_emission_render_fwd(const void* packed, int d_filter, int n_linear,
+int sunerf_emission_render_fwd(const void* packed, int d_filter, int n_linear, int precision,
                                const float* rays_o, const float* rays_d, const float* times,
                                const float* z_vals, int64_t n_rays, int n_samples,
                                float* image, float* weights, float* absorption, float* raw,

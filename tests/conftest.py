@@ -33,3 +33,11 @@ def params_from_golden(g, prefix):
     sd = {k[len(prefix):].replace('__', '.'): v for k, v in g.items() if k.startswith(prefix)}
     import sunerf_oracle as orc
     return orc.params_from_state_dict(sd, '')
+
+
+@pytest.fixture(params=['fast', 'exact'])
+def precision(request, monkeypatch):
+    """Runs a test under both forward arithmetics (include/sunerf_hip.h: SUNERF_PRECISION_*): packed models pick the mode
+    up from the environment when they are created."""
+    monkeypatch.setenv('SUNERF_FORWARD_PRECISION', request.param)
+    return request.param

@@ -42,7 +42,7 @@ def _oracle_grads(params, o, d, t, z, g_image, g_reg_const):
 
 
 @pytest.mark.parametrize('d_filter,n_layers,S', [(64, 3, 32), (64, 8, 40), (128, 4, 64), (256, 8, 32), (64, 1, 32), (64, 2, 96), (512, 8, 32), (512, 2, 64), (512, 1, 32)])
-def test_render_pass_backward(ops, d_filter, n_layers, S):
+def test_render_pass_backward(ops, d_filter, n_layers, S, precision):
     params, o, d, t, z = _case(d_filter, n_layers, S)
     n = o.shape[0]
     g_image = torch.randn(n) * 1e-3

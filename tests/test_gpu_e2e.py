@@ -32,7 +32,7 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize('name,d_filter,n_c,n_f', [('g5_emission_e2e', 64, 32, 32), ('g5b_emission_d256', 256, 32, 64)])
-def test_forward_matches_reference(name, d_filter, n_c, n_f):
+def test_forward_matches_reference(name, d_filter, n_c, n_f, precision):
     g = load_golden(name)
     mod = _module(g, d_filter, n_c, n_f)
     out = mod(g['rays_o'].cuda(), g['rays_d'].cuda(), g['times'].cuda())
@@ -46,8 +46,10 @@ def test_forward_matches_reference(name, d_filter, n_c, n_f):
     assert (out['z_vals_hierarchical'].cpu() - g['out__z_vals_hierarchical']).abs().max().item() < 2e-4
     for k in ('fine_image', 'image', 'height_map', 'absorption_map'):
         assert rel(out[k], g['out__' + k]) < 2e-4, k
+    # (golden rays have |d| != 1: samples far from the origin amplify the error of 1 - absorption, see test_gpu_stages)
+    tol = 2e-4 if precision == 'exact' else 1e-3
     assert (out['regularization'].cpu() - g['out__regularization']).abs().max().item() \
-        < 2e-4 * g['out__regularization'].abs().max().item() + 1e-7
+        < tol * g['out__regularization'].abs().max().item() + 1e-7
 
 
 def test_state_dict_keys_match_reference():
@@ -81,7 +83,7 @@ def test_repack_after_inplace_update():
     assert rel(b, want) < 1e-5
 
 
-def test_training_step_matches_reference_loss_and_grads():
+def test_training_step_matches_reference_loss_and_grads(precision):
     """EmissionSuNeRFModule.training_step + backward vs the reference's own loss and parameter gradients (g5)."""
     from sunerf.model.sunerf import EmissionSuNeRFModule
     g = load_golden('g5_emission_e2e')

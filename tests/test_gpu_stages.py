@@ -49,7 +49,7 @@ def test_sample_z_bit_exact(ops):
 
 @pytest.mark.parametrize('d_filter,n_layers', [(64, 8), (128, 3), (256, 8), (64, 1), (64, 2)])
 @pytest.mark.parametrize('S', [32, 40, 96])
-def test_render_pass_vs_oracle(ops, d_filter, n_layers, S):
+def test_render_pass_vs_oracle(ops, d_filter, n_layers, S, precision):
     torch.manual_seed(d_filter + S)
     params = orc.init_params(d_filter=d_filter, n_layers=n_layers, seed=3)
     o, d = orc.synthetic_rays(5)                      # 25 rays: not a multiple of 4 -> ragged last group
@@ -68,10 +68,14 @@ def test_render_pass_vs_oracle(ops, d_filter, n_layers, S):
     assert rel_err(out['height_map'], (ref['weights'] * dist_pts).sum(-1)) < 1e-4
     assert rel_err(out['absorption_map'], (1 - ref['regularizing_quantity']).sum(-1)) < 1e-4
     reg = torch.relu(dist_pts - 1.2) * (1 - ref['regularizing_quantity'])
-    assert (out['regularization'].cpu() - reg).abs().max().item() <= 1e-4 * reg.abs().max().item() + 1e-7
+    # these rays have |d| != 1, so the samples sit up to 40 radii from the origin and relu(|p| - 1.2) multiplies the error of
+    # (1 - absorption) by up to 40: 1e-4 of the maximum needs the exact arithmetic; the fp8-correction mode (raw output
+    # within 2e-5, asserted above) gets 5e-4 on this amplified quantity
+    tol = 1e-4 if precision == 'exact' else 5e-4
+    assert (out['regularization'].cpu() - reg).abs().max().item() <= tol * reg.abs().max().item() + 1e-7
 
 
-def test_render_pass_golden_mlp(ops):
+def test_render_pass_golden_mlp(ops, precision):
     """MLP output against the REFERENCE's own output (fixture g2), large time coordinates included."""
     g = load_golden('g2_mlp')
     params = params_from_golden(g, 'net__')
