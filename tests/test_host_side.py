@@ -50,8 +50,13 @@ def test_argument_errors_without_gpu(lib):
     assert lib.sunerf_sample_z(0, None, None, None, None, 0, 8, 1.3, 1.0, None, None) == 0       # empty batch: nothing to do
     assert lib.sunerf_sample_z(7, None, None, None, None, 0, 8, 1.3, 1.0, None, None) == -2      # unknown sampler kind
     assert lib.sunerf_hier_resample(None, None, None, 0, 4, 8, 8, None, None, None) == -1
-    assert lib.sunerf_emission_render_fwd(None, 256, 9, None, None, None, None, 4, 8, None, None, None, None, None, None,
+    assert lib.sunerf_emission_render_fwd(None, 256, 9, 0, None, None, None, None, 4, 8, None, None, None, None, None, None,
                                           None, 1.2, None, None, 0, None) == -1
+    # precision: an unknown mode is a bad argument; the fp8-correction mode does not exist at d_filter = 512
+    assert lib.sunerf_emission_render_fwd(None, 256, 9, 5, None, None, None, None, 4, 8, None, None, None, None, None, None,
+                                          None, 1.2, None, None, 0, None) == -1
+    assert lib.sunerf_emission_render_fwd(None, 512, 9, 0, None, None, None, None, 4, 8, None, None, None, None, None, None,
+                                          None, 1.2, None, None, 0, None) == -2
     assert lib.sunerf_render_workspace_bytes(256) == 0 and lib.sunerf_render_workspace_bytes(512) == 1024 * 4 * 32 * 2048
 
 
