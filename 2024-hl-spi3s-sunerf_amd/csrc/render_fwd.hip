@@ -430,6 +430,8 @@ __device__ __forceinline__ void epi_stage_c8(const PairTmp& t, int p, int FP, ha
   // the 64-deep fp8 operands of a group (4 fragments = 2 tiles) are collected in the VGPR tuples w8h / w8l and moved to
   // the (AGPR-resident) operand set in one piece when the group is complete: partial writes to an 8-register AGPR tuple
   // make the allocator copy the tuple around
+  // (v_cvt_scalef32_pk_fp8_f32 would fold the 2^11 into the conversion, but it flushes what lands in the fp8 subnormal
+  // range: measured 10x the output error -- so multiply, then convert with the subnormal-preserving instruction)
   if (dq & 1) {   // the word selector of the builtin must be a literal
     w8h[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.s0, t.s1, w8h[d], true);
     w8l[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.r0 * 2048.f, t.r1 * 2048.f, w8l[d], true);
@@ -498,7 +500,7 @@ struct Mlp8 : Mlp<D> {
     constexpr int SEGS = 6 * ((KS - 2) / 4) + ((KS - 2) % 4);        // segments before the deadline
     constexpr int PER = SEGS >= 16 ? 0 : (8 + SEGS - 1) / SEGS;      // 0: one micro-op per two segments (A+B | C)
     half8 ch0, ch1;
-    PairTmp t[PER == 0 ? 1 : PER];
+    PairTmp t[PER == 0 ? 2 : PER];
     // the block-scaled fp8 instruction sums with ~17 bits (probe: 8e-6 relative on a 64-deep sum): harmless for the
     // corrections themselves (2^-12 of the result) but not for a running sum of order one passed through it, so they
     // get their own accumulator, added once per tile
@@ -527,21 +529,26 @@ struct Mlp8 : Mlp<D> {
         }
         if (HAS_PREV) {
           if (PER == 0) {
-            const int op = seg >> 1;
-            if (op < 8) {
-              if ((seg & 1) == 0) { epi_stage_a<STASH>(prev, op, t[0]); epi_stage_b<STASH>(t[0]); }
-              else epi_stage_c8<STASH>(t[0], op, FP, yhi, yh8, yl8, w8h, w8l, ch0, ch1, st, st_off, cos_delta);
+            // micro-op i: stage A in segment 2 i, B in 2 i + 1, C in 2 i + 2 (beside stage A of op i + 1): every
+            // segment holds independent pieces, so the transcendental / conversion result latencies are covered
+            const int i = seg >> 1;
+            if ((seg & 1) == 0) {
+              if (i < 8) epi_stage_a<STASH>(prev, i, t[i & 1]);
+              if (i >= 1 && i <= 8) epi_stage_c8<STASH>(t[(i - 1) & 1], i - 1, FP, yhi, yh8, yl8, w8h, w8l, ch0, ch1, st, st_off, cos_delta);
+            } else if (i < 8) {
+              epi_stage_b<STASH>(t[i & 1]);
             }
           } else {
 #pragma unroll
-            for (int e = 0; e < PER; ++e) {
-              const int op = seg * PER + e;
-              if (op < 8) {
-                epi_stage_a<STASH>(prev, op, t[e]);
-                epi_stage_b<STASH>(t[e]);
-                epi_stage_c8<STASH>(t[e], op, FP, yhi, yh8, yl8, w8h, w8l, ch0, ch1, st, st_off, cos_delta);
-              }
-            }
+            for (int e = 0; e < PER; ++e)
+              if (seg * PER + e < 8) epi_stage_a<STASH>(prev, seg * PER + e, t[e]);
+#pragma unroll
+            for (int e = 0; e < PER; ++e)
+              if (seg * PER + e < 8) epi_stage_b<STASH>(t[e]);
+#pragma unroll
+            for (int e = 0; e < PER; ++e)
+              if (seg * PER + e < 8)
+                epi_stage_c8<STASH>(t[e], seg * PER + e, FP, yhi, yh8, yl8, w8h, w8l, ch0, ch1, st, st_off, cos_delta);
           }
         }
         // weight stream: two pieces per group behind the acquire (page + 3 into the slot everyone left)
