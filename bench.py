@@ -278,11 +278,15 @@ def main():
 
     if rank == 0:
         achieved = rays_per_step * args.samples * flops_per_sample / (step_ms * 1e-3) / 1e12
+        # matrix-pipe work of the forward per algorithmic flop: EXACT 3 fp16 products; FAST 1 fp16 product + two 64-deep
+        # fp8 instructions per four 16-deep steps (measured 84 cycles each against 4 x 32: tools/probes/bench_mfma_mix.hip)
+        fast = D_FILTER <= 256 and os.environ.get('SUNERF_FORWARD_PRECISION', 'fast').lower() != 'exact'
+        fwd_factor = 1.0 + 2.0 * 84.0 / 128.0 if fast else 3.0
         if args.mode == 'fwd':
-            executed_factor = 3.0
+            executed_factor = fwd_factor
         else:
             dgrad = flops_bwd(D_FILTER) - flops_fwd(D_FILTER)
-            executed_factor = (3.0 * flops_fwd(D_FILTER) + 2.0 * dgrad + flops_fwd(D_FILTER)) / flops_per_sample
+            executed_factor = (fwd_factor * flops_fwd(D_FILTER) + 2.0 * dgrad + flops_fwd(D_FILTER)) / flops_per_sample
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
         if os.path.exists(tpath):
@@ -297,7 +301,11 @@ def main():
             'metric': f'ray-samples/sec ({what}, fused emission renderer)', 'value': value, 'unit': 'ray-samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 (forward: fp16 hi/lo split, 3 MFMA per product; backward: fp16 MFMA; fp32 accumulate and parameters)',
+            'dtype': ('f32 (forward: every operand split into an fp16 head and an exact remainder, head products on the fp16 '
+                      'matrix cores + ' + ('block-scaled fp8 products for the two cross terms' if D_FILTER <= 256 and
+                                           os.environ.get('SUNERF_FORWARD_PRECISION', 'fast').lower() != 'exact'
+                                           else 'fp16 products for the two cross terms')
+                      + '; backward: fp16 MFMA, W^T hi + lo; fp32 accumulate and parameters)'),
             'data': 'synthetic',
             'config': {'workload': (f'emission render {what}, {args.res}x{args.res} frame x {args.samples} samples/ray, '
                                     f'{N_LAYERS}x{D_FILTER} sine MLP, '
@@ -309,8 +317,8 @@ def main():
                          'kernel': kernel_name, 'step_ms_hip_events': step_ms,
                          'flops_per_sample': flops_per_sample,
                          'frac_of_f32_mfma_peak': achieved / PEAK_F32_MFMA_TFLOPS,
-                         # what the matrix pipe actually executes: forward products are 3 fp16 MFMAs (hi/lo split), the
-                         # data gradient 2 (hi + lo weights), the weight gradient 1
+                         # matrix-pipe time actually spent, in fp16-MFMA equivalents: forward see fwd_factor, the data
+                         # gradient 2 (hi + lo weights), the weight gradient 1
                          'executed_frac': achieved * executed_factor / PEAK_F16_DENSE_TFLOPS,
                          # average HBM rate of the step against the 8 TB/s peak (PMC traffic of this configuration)
                          'hbm_frac': (traffic / (step_ms * 1e-3) / 8e12) if traffic else None},
