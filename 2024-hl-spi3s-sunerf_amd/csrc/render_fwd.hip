@@ -432,12 +432,14 @@ __device__ __forceinline__ void epi_stage_c8(const PairTmp& t, int p, int FP, ha
   // make the allocator copy the tuple around
   // (v_cvt_scalef32_pk_fp8_f32 would fold the 2^11 into the conversion, but it flushes what lands in the fp8 subnormal
   // range: measured 10x the output error -- so multiply, then convert with the subnormal-preserving instruction)
+  // (two v_mul_f32: the packed v_pk_mul_f32 measured slower here)
+  const float rs0 = t.r0 * 2048.f, rs1 = t.r1 * 2048.f;
   if (dq & 1) {   // the word selector of the builtin must be a literal
     w8h[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.s0, t.s1, w8h[d], true);
-    w8l[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.r0 * 2048.f, t.r1 * 2048.f, w8l[d], true);
+    w8l[d] = __builtin_amdgcn_cvt_pk_fp8_f32(rs0, rs1, w8l[d], true);
   } else {
     w8h[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.s0, t.s1, 0, false);
-    w8l[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.r0 * 2048.f, t.r1 * 2048.f, 0, false);
+    w8l[d] = __builtin_amdgcn_cvt_pk_fp8_f32(rs0, rs1, 0, false);
   }
   if (STASH) {
     if (p < 4) { ch0[2 * p] = t.cpk[0]; ch0[2 * p + 1] = t.cpk[1]; }
@@ -465,9 +467,12 @@ struct Mlp8 : Mlp<D> {
   static constexpr int PIECES = Ring<D>::PIECES;
   static_assert(PAGE_STEPS == KS && KS % 4 == 0, "fp8c: a hidden tile is one page of whole groups");
 
-  struct Pipe8 {            // A operands of the NEXT group to execute
-    half8 a16[4];
-    v8i al8, ah8;
+  // A operands of the next DIST groups (in-place refill behind the consuming instruction)
+  static constexpr int DIST = 1;   // (2 was measured: no faster at d = 256, and it costs 32 registers)
+  static_assert(G % DIST == 0, "operand slot of a group must be a compile-time constant");
+  struct Pipe8 {
+    half8 a16[DIST][4];
+    v8i al8[DIST], ah8[DIST];
   };
   struct Scales { int a_lo, a_hi; };   // E8M0 block scales of the two fp8 A operands of a layer: 127 - (sh + 11), 127 - sh
 
@@ -477,13 +482,18 @@ struct Mlp8 : Mlp<D> {
     v8i r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return r;
   }
-  // all operands of the group at ring position `ring_step` (a layer's first group: nothing prefetched it)
+  // all operands of the first DIST groups from ring position `ring_step` on (a layer stack's start: nothing prefetched them)
   static __device__ __forceinline__ void preload(const Pipe& p, Pipe8& q, int ring_step) {
-    const char* b = group_ptr(p, ring_step);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) q.a16[i] = *(const half8*)(b + i * 1024);
-    q.al8 = load8(b + 4096);
-    q.ah8 = load8(b + 6144);
+    for (int d = 0; d < DIST; ++d) {
+      int rs = ring_step + 4 * d;
+      rs = rs >= RING_STEPS ? rs - RING_STEPS : rs;
+      const char* b = group_ptr(p, rs);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q.a16[d][i] = *(const half8*)(b + i * 1024);
+      q.al8[d] = load8(b + 4096);
+      q.ah8[d] = load8(b + 6144);
+    }
   }
 
   // One hidden / out tile (KS k-steps = G groups = one page).  Per group six matrix instructions on one accumulator: four
@@ -507,25 +517,26 @@ struct Mlp8 : Mlp<D> {
     f32x16 accc = {0};
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      // ring position (k-steps) of the next group's operands
+      // ring position (k-steps) of the operands requested while this group executes
+      const int slot8 = g % DIST;
       int nrs;
-      if (RS0 >= 0) nrs = (RS0 + 4 * (g + 1)) % RING_STEPS;
-      else { nrs = p.rstep + 4 * (g + 1); nrs = nrs >= RING_STEPS ? nrs - RING_STEPS : nrs; }
+      if (RS0 >= 0) nrs = (RS0 + 4 * (g + DIST)) % RING_STEPS;
+      else { nrs = p.rstep + 4 * (g + DIST); nrs = nrs >= RING_STEPS ? nrs - RING_STEPS : nrs; }
       const char* nb = group_ptr(p, nrs);
-      if (g == G - 1) {
-        // the refills below read the next page: acquire it (its successor's pieces, and in training the 4 stash stores of
-        // this tile's epilogue, may still be in flight)
-        ring.template acquire<(STASH && HAS_PREV) ? 4 : 0>();
+      if (g == G - DIST) {
+        // the refills from here on read the next page: acquire it.  Of the page after it, 2 + 2 (G - DIST) pieces have been
+        // issued by now (two per group since the previous tile's last group); anything else in flight is younger still.
+        ring.template acquire<-2 * (DIST - 1)>();
       }
 #pragma unroll
       for (int sg = 0; sg < 6; ++sg) {
         const int seg = 6 * g + sg;
         if (sg < 4) {
-          acc = mfma16(q.a16[sg], xhi[4 * g + sg], acc);
+          acc = mfma16(q.a16[slot8][sg], xhi[4 * g + sg], acc);
         } else if (sg == 4) {
-          accc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(q.al8, xh8[g], accc, 0, 0, 0, sc.a_lo, 0, 127);
+          accc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(q.al8[slot8], xh8[g], accc, 0, 0, 0, sc.a_lo, 0, 127);
         } else {
-          accc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(q.ah8, xl8[g], accc, 0, 0, 0, sc.a_hi, 0, 127 - 11);
+          accc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(q.ah8[slot8], xl8[g], accc, 0, 0, 0, sc.a_hi, 0, 127 - 11);
         }
         if (HAS_PREV) {
           if (PER == 0) {
@@ -557,9 +568,9 @@ struct Mlp8 : Mlp<D> {
           if (piece < PIECES) M::issue_piece_dyn(ring, piece);
         }
         // in-place prefetch of the next group's operand
-        if (sg < 4) q.a16[sg] = *(const half8*)(nb + sg * 1024);
-        else if (sg == 4) q.al8 = load8(nb + 4096);
-        else q.ah8 = load8(nb + 6144);
+        if (sg < 4) q.a16[slot8][sg] = *(const half8*)(nb + sg * 1024);
+        else if (sg == 4) q.al8[slot8] = load8(nb + 4096);
+        else q.ah8[slot8] = load8(nb + 6144);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
