@@ -477,6 +477,29 @@ struct Mlp8 : Mlp<D> {
   struct Scales { int a_lo, a_hi; };   // E8M0 block scales of the two fp8 A operands of a layer: 127 - (sh + 11), 127 - sh
 
   static __device__ __forceinline__ const char* group_ptr(const Pipe& p, int ring_step) { return p.frag + ring_step * 2048; }
+  // LDS addresses of a tile's operand reads as (one of three bases) + 16-bit immediate.  The bases are made opaque once per
+  // tile: otherwise the compiler treats every `frag + constant` as a loop invariant of the chunk loop, keeps ~30 of them
+  // in VGPRs and evicts operand tuples from the AGPRs to make room.
+  typedef const __attribute__((address_space(3))) char* lds_cptr;   // 32-bit LDS pointer: keeps the reads ds_read, not flat
+  struct LdsBases {
+    lds_cptr b[3];
+    __device__ __forceinline__ explicit LdsBases(const Pipe& p) {
+      b[0] = (lds_cptr)(unsigned)(uintptr_t)p.frag;
+      b[1] = b[0] + 49152;
+      b[2] = b[0] + 98304;
+      asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
+    }
+    // byte offset (a literal when the ring position is static) -> address
+    __device__ __forceinline__ lds_cptr at(int off) const {
+      return off < 49152 ? b[0] + off : (off < 98304 ? b[1] + (off - 49152) : b[2] + (off - 98304));
+    }
+  };
+  static __device__ __forceinline__ half8 lds_half8(lds_cptr q) { return *(const __attribute__((address_space(3))) half8*)q; }
+  static __device__ __forceinline__ v8i lds_v8i(lds_cptr q0, lds_cptr q1) {
+    const v4i lo = *(const __attribute__((address_space(3))) v4i*)q0, hi = *(const __attribute__((address_space(3))) v4i*)q1;
+    v8i r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+  }
   static __device__ __forceinline__ v8i load8(const char* q) {
     const v4i lo = *(const v4i*)q, hi = *(const v4i*)(q + 1024);
     v8i r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -511,6 +534,7 @@ struct Mlp8 : Mlp<D> {
     constexpr int PER = SEGS >= 16 ? 0 : (8 + SEGS - 1) / SEGS;      // 0: one micro-op per two segments (A+B | C)
     half8 ch0, ch1;
     PairTmp t[PER == 0 ? 2 : PER];
+    const LdsBases lb(p);
     // the block-scaled fp8 instruction sums with ~17 bits (probe: 8e-6 relative on a 64-deep sum): harmless for the
     // corrections themselves (2^-12 of the result) but not for a running sum of order one passed through it, so they
     // get their own accumulator, added once per tile
@@ -522,7 +546,8 @@ struct Mlp8 : Mlp<D> {
       int nrs;
       if (RS0 >= 0) nrs = (RS0 + 4 * (g + DIST)) % RING_STEPS;
       else { nrs = p.rstep + 4 * (g + DIST); nrs = nrs >= RING_STEPS ? nrs - RING_STEPS : nrs; }
-      const char* nb = group_ptr(p, nrs);
+      const char* nb = RS0 >= 0 ? nullptr : group_ptr(p, nrs);      // run-time ring position (d = 64): one add per group
+      const int nbo = nrs * 2048;                                   // static ring position: base + immediate
       if (g == G - DIST) {
         // the refills from here on read the next page: acquire it.  Of the page after it, 2 + 2 (G - DIST) pieces have been
         // issued by now (two per group since the previous tile's last group); anything else in flight is younger still.
@@ -568,9 +593,15 @@ struct Mlp8 : Mlp<D> {
           if (piece < PIECES) M::issue_piece_dyn(ring, piece);
         }
         // in-place prefetch of the next group's operand
-        if (sg < 4) q.a16[slot8][sg] = *(const half8*)(nb + sg * 1024);
-        else if (sg == 4) q.al8[slot8] = load8(nb + 4096);
-        else q.ah8[slot8] = load8(nb + 6144);
+        if (RS0 >= 0) {
+          if (sg < 4) q.a16[slot8][sg] = lds_half8(lb.at(nbo + sg * 1024));
+          else if (sg == 4) q.al8[slot8] = lds_v8i(lb.at(nbo + 4096), lb.at(nbo + 5120));
+          else q.ah8[slot8] = lds_v8i(lb.at(nbo + 6144), lb.at(nbo + 7168));
+        } else {
+          if (sg < 4) q.a16[slot8][sg] = *(const half8*)(nb + sg * 1024);
+          else if (sg == 4) q.al8[slot8] = load8(nb + 4096);
+          else q.ah8[slot8] = load8(nb + 6144);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
