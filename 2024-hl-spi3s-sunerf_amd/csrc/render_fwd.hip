@@ -528,13 +528,16 @@ struct Mlp8 : Mlp<D> {
   template <bool HAS_PREV, int RS0, bool STASH>
   static __device__ __forceinline__ f32x16 tile8(Ring<D>& ring, Pipe& p, Pipe8& q, f32x16 acc, const half8* xhi,
                                                  const v8i* xh8, const v8i* xl8, const Scales sc, const f32x16& prev,
-                                                 int FP, half8* yhi, v8i* yh8, v8i* yl8, v8i& w8h, v8i& w8l, Rsrc st,
+                                                 f32x16& pc /* in: correction accumulator of prev; out: ours */, int FP, half8* yhi, v8i* yh8, v8i* yl8, v8i& w8h, v8i& w8l, Rsrc st,
                                                  int st_off, int cos_delta) {
     constexpr int SEGS = 6 * ((KS - 2) / 4) + ((KS - 2) % 4);        // segments before the deadline
     constexpr int PER = SEGS >= 16 ? 0 : (8 + SEGS - 1) / SEGS;      // 0: one micro-op per two segments (A+B | C)
     half8 ch0, ch1;
     PairTmp t[PER == 0 ? 2 : PER];
+    static_assert(PER != 0 || 2 + 2 * 8 < SEGS, "shifted epilogue schedule must still meet the deadline");
     const LdsBases lb(p);
+    f32x16 pv;
+    if (PER != 0) pv = prev + pc;        // short tiles (d <= 128): summed up front
     // the block-scaled fp8 instruction sums with ~17 bits (probe: 8e-6 relative on a 64-deep sum): harmless for the
     // corrections themselves (2^-12 of the result) but not for a running sum of order one passed through it, so they
     // get their own accumulator, added once per tile
@@ -565,19 +568,22 @@ struct Mlp8 : Mlp<D> {
         }
         if (HAS_PREV) {
           if (PER == 0) {
-            // micro-op i: stage A in segment 2 i, B in 2 i + 1, C in 2 i + 2 (beside stage A of op i + 1): every
+            // The previous tile's two accumulators are summed in segment 2, behind two of this tile's matrix instructions
+            // (summing at the end of their own tile idles the wave through the latency of its last 16-pass instruction).
+            // Micro-op i: stage A in segment 2 + 2 i, B in 3 + 2 i, C in 4 + 2 i (beside stage A of op i + 1): every
             // segment holds independent pieces, so the transcendental / conversion result latencies are covered
-            const int i = seg >> 1;
-            if ((seg & 1) == 0) {
-              if (i < 8) epi_stage_a<STASH>(prev, i, t[i & 1]);
+            if (seg == 2) pv = prev + pc;
+            const int i = (seg - 2) >> 1;
+            if (seg >= 2 && ((seg - 2) & 1) == 0) {
+              if (i < 8) epi_stage_a<STASH>(pv, i, t[i & 1]);
               if (i >= 1 && i <= 8) epi_stage_c8<STASH>(t[(i - 1) & 1], i - 1, FP, yhi, yh8, yl8, w8h, w8l, ch0, ch1, st, st_off, cos_delta);
-            } else if (i < 8) {
+            } else if (seg >= 2 && i < 8) {
               epi_stage_b<STASH>(t[i & 1]);
             }
           } else {
 #pragma unroll
             for (int e = 0; e < PER; ++e)
-              if (seg * PER + e < 8) epi_stage_a<STASH>(prev, seg * PER + e, t[e]);
+              if (seg * PER + e < 8) epi_stage_a<STASH>(pv, seg * PER + e, t[e]);
 #pragma unroll
             for (int e = 0; e < PER; ++e)
               if (seg * PER + e < 8) epi_stage_b<STASH>(t[e]);
@@ -609,7 +615,8 @@ struct Mlp8 : Mlp<D> {
       p.rstep += KS;
       if (p.rstep >= RING_STEPS) p.rstep -= RING_STEPS;
     }
-    return acc + accc;
+    pc = accc;
+    return acc;
   }
 
   // in-layer tile (6 k-steps, classic hi | lo weights and encoding operands) with the fp8c epilogue format
@@ -698,8 +705,8 @@ struct Mlp8 : Mlp<D> {
   template <bool STASH>
   static __device__ __forceinline__ f32x16 hidden_layer(Ring<D>& ring, Pipe& p, Pipe8& q, const float* bias, int h,
                                                         const Scales sc, half8* xhi, v8i* xh8, v8i* xl8, half8* yhi,
-                                                        v8i* yh8, v8i* yl8, v8i& w8h, v8i& w8l, const f32x16& carry, Rsrc st,
-                                                        int st_prev, int st_own) {
+                                                        v8i* yh8, v8i* yl8, v8i& w8h, v8i& w8l, const f32x16& carry, f32x16& pc,
+                                                        Rsrc st, int st_prev, int st_own) {
     f32x16 prev = carry;
     constexpr int CD = KS * 1024;
     constexpr int XL = 2 * NT - 2;
@@ -709,9 +716,9 @@ struct Mlp8 : Mlp<D> {
 #define SUNERF_TILE8(UU)                                                                                             \
       if (U == UU) {                                                                                                   \
         constexpr int RS = RS_HIDDEN < 0 ? -1 : (RS_HIDDEN + UU * KS) % RING_STEPS;                                    \
-        if (UU == 0) acc = tile8<true, RS, STASH>(ring, p, q, acc, xhi, xh8, xl8, sc, prev, XL, xhi, xh8, xl8, w8h, w8l, st, \
+        if (UU == 0) acc = tile8<true, RS, STASH>(ring, p, q, acc, xhi, xh8, xl8, sc, prev, pc, XL, xhi, xh8, xl8, w8h, w8l, st, \
                                                   st_prev + XL * 1024, CD);                                           \
-        else acc = tile8<true, RS, STASH>(ring, p, q, acc, xhi, xh8, xl8, sc, prev, 2 * UU - 2, yhi, yh8, yl8, w8h, w8l, st, \
+        else acc = tile8<true, RS, STASH>(ring, p, q, acc, xhi, xh8, xl8, sc, prev, pc, 2 * UU - 2, yhi, yh8, yl8, w8h, w8l, st, \
                                           st_own + (2 * UU - 2) * 1024, CD);                                          \
       }
       SUNERF_TILE8(0) SUNERF_TILE8(1) SUNERF_TILE8(2) SUNERF_TILE8(3) SUNERF_TILE8(4) SUNERF_TILE8(5) SUNERF_TILE8(6) SUNERF_TILE8(7)
@@ -724,10 +731,11 @@ struct Mlp8 : Mlp<D> {
   template <bool STASH>
   static __device__ __forceinline__ f32x16 out_layer(Ring<D>& ring, Pipe& p, Pipe8& q, const float* bias, int h,
                                                      const Scales sc, half8* xhi, v8i* xh8, v8i* xl8, v8i& w8h, v8i& w8l,
-                                                     const f32x16& carry, Rsrc st, int st_prev) {
+                                                     const f32x16& carry, f32x16& pc, Rsrc st, int st_prev) {
     constexpr int XL = 2 * NT - 2;
-    return tile8<true, RS_HIDDEN, STASH>(ring, p, q, bias_tile(bias, h), xhi, xh8, xl8, sc, carry, XL, xhi, xh8, xl8, w8h, w8l,
-                                         st, st_prev + XL * 1024, KS * 1024);
+    const f32x16 r = tile8<true, RS_HIDDEN, STASH>(ring, p, q, bias_tile(bias, h), xhi, xh8, xl8, sc, carry, pc, XL, xhi, xh8,
+                                                   xl8, w8h, w8l, st, st_prev + XL * 1024, KS * 1024);
+    return r + pc;
   }
 };
 
@@ -817,6 +825,7 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
         v8i w8h, w8l;                                          // fp8 operands of the group under construction
         f32x16 carry = M8::template in_layer<STASH>(ring, pipe, bias, h, e_hi, e_lo, xa_hi, xa_h8, xa_l8, w8h, w8l, st, (int)SL.h_off(0));
         typename M8::Pipe8 q8;
+        f32x16 pc = {0};                                       // correction accumulator of the pending tile (in layer: none)
         M8::preload(pipe, q8, M::RS_HIDDEN >= 0 ? M::RS_HIDDEN : pipe.rstep);
         auto scales = [&](int l) {
           const int sh = shp[l];
@@ -826,17 +835,17 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
         int l = 1;
         for (; l + 1 < a.n_linear - 1; l += 2) {
           carry = M8::template hidden_layer<STASH>(ring, pipe, q8, bias + (size_t)l * D, h, scales(l), xa_hi, xa_h8, xa_l8, xb_hi,
-                                                   xb_h8, xb_l8, w8h, w8l, carry, st, (int)SL.h_off(l - 1), (int)SL.h_off(l));
+                                                   xb_h8, xb_l8, w8h, w8l, carry, pc, st, (int)SL.h_off(l - 1), (int)SL.h_off(l));
           carry = M8::template hidden_layer<STASH>(ring, pipe, q8, bias + (size_t)(l + 1) * D, h, scales(l + 1), xb_hi, xb_h8,
-                                                   xb_l8, xa_hi, xa_h8, xa_l8, w8h, w8l, carry, st, (int)SL.h_off(l), (int)SL.h_off(l + 1));
+                                                   xb_l8, xa_hi, xa_h8, xa_l8, w8h, w8l, carry, pc, st, (int)SL.h_off(l), (int)SL.h_off(l + 1));
         }
         if (l < a.n_linear - 1) {
           carry = M8::template hidden_layer<STASH>(ring, pipe, q8, bias + (size_t)l * D, h, scales(l), xa_hi, xa_h8, xa_l8, xb_hi,
-                                                   xb_h8, xb_l8, w8h, w8l, carry, st, (int)SL.h_off(l - 1), (int)SL.h_off(l));
-          out = M8::template out_layer<STASH>(ring, pipe, q8, obias, h, scales(a.n_linear - 1), xb_hi, xb_h8, xb_l8, w8h, w8l, carry, st,
+                                                   xb_h8, xb_l8, w8h, w8l, carry, pc, st, (int)SL.h_off(l - 1), (int)SL.h_off(l));
+          out = M8::template out_layer<STASH>(ring, pipe, q8, obias, h, scales(a.n_linear - 1), xb_hi, xb_h8, xb_l8, w8h, w8l, carry, pc, st,
                                               (int)SL.h_off(l));
         } else {
-          out = M8::template out_layer<STASH>(ring, pipe, q8, obias, h, scales(a.n_linear - 1), xa_hi, xa_h8, xa_l8, w8h, w8l, carry, st,
+          out = M8::template out_layer<STASH>(ring, pipe, q8, obias, h, scales(a.n_linear - 1), xa_hi, xa_h8, xa_l8, w8h, w8l, carry, pc, st,
                                               (int)SL.h_off(l - 1));
         }
       } else if constexpr (!M::SPILL) {   // exact mode: three fp16 products per term (hi*hi + hi*lo + lo*hi)
