@@ -438,8 +438,10 @@ __device__ __forceinline__ void epi_stage_c8(const PairTmp& t, int p, int FP, ha
     w8h[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.s0, t.s1, w8h[d], true);
     w8l[d] = __builtin_amdgcn_cvt_pk_fp8_f32(rs0, rs1, w8l[d], true);
   } else {
-    w8h[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.s0, t.s1, 0, false);
-    w8l[d] = __builtin_amdgcn_cvt_pk_fp8_f32(rs0, rs1, 0, false);
+    // (merging into the dword's stale content instead of a fresh 0 saves a v_mov per conversion: the other word is
+    // rewritten by the next micro-op anyway)
+    w8h[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.s0, t.s1, w8h[d], false);
+    w8l[d] = __builtin_amdgcn_cvt_pk_fp8_f32(rs0, rs1, w8l[d], false);
   }
   if (STASH) {
     if (p < 4) { ch0[2 * p] = t.cpk[0]; ch0[2 * p + 1] = t.cpk[1]; }
@@ -822,7 +824,7 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
             M::load_frag(pipe, s, rs);
           }
         }
-        v8i w8h, w8l;                                          // fp8 operands of the group under construction
+        v8i w8h = {0}, w8l = {0};                              // fp8 operands of the group under construction
         f32x16 carry = M8::template in_layer<STASH>(ring, pipe, bias, h, e_hi, e_lo, xa_hi, xa_h8, xa_l8, w8h, w8l, st, (int)SL.h_off(0));
         typename M8::Pipe8 q8;
         f32x16 pc = {0};                                       // correction accumulator of the pending tile (in layer: none)
