@@ -486,7 +486,7 @@ struct Mlp8 : Mlp<D> {
   struct LdsBases {
     lds_cptr b[3];
     __device__ __forceinline__ explicit LdsBases(const Pipe& p) {
-      b[0] = (lds_cptr)(unsigned)(uintptr_t)p.frag;
+      b[0] = (lds_cptr)(uintptr_t)(unsigned)(uintptr_t)p.frag;   // low 32 bits of a generic LDS address = the LDS address
       b[1] = b[0] + 49152;
       b[2] = b[0] + 98304;
       asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
