@@ -420,12 +420,17 @@ __device__ __forceinline__ void pin_agpr8(v8i& f) { asm volatile("" : "+a"(f)); 
 // Stage C of a pair micro-op, fp8c operand format: the finished values go into fragment FP + (p >> 2) of the output set as
 // fp16 head (yhi) and as two fp8 words -- the head itself and the remainder scaled by 2^11 -- of the 64-deep fp8 operands
 // (group = fragment / 4; dword 2 (fragment % 4) + (p % 4) / 2, 16-bit word (p % 4) % 2).
-template <bool STASH>
+// SPILL_OUT (d = 512, one operand set): the finished fragment / group goes to this wave's scratch instead of registers --
+// per group 8 KiB: [4 x 1 KiB fp16 heads][2 x 1 KiB fp8 heads][2 x 1 KiB fp8 remainders] (the weight stream's arrangement);
+// `th` collects the fragment under construction.
+template <bool STASH, bool SPILL_OUT = false>
 __device__ __forceinline__ void epi_stage_c8(const PairTmp& t, int p, int FP, half8* yhi, v8i* yh8, v8i* yl8, v8i& w8h,
-                                             v8i& w8l, half8& ch0, half8& ch1, Rsrc st, int st_off, int cos_delta) {
+                                             v8i& w8l, half8& ch0, half8& ch1, Rsrc st, int st_off, int cos_delta,
+                                             Rsrc sc = Rsrc(), half8* th = nullptr) {
   const int f = FP + (p >> 2), dq = p & 3;                 // literals after unrolling
-  yhi[f][2 * dq] = t.hi[0];
-  yhi[f][2 * dq + 1] = t.hi[1];
+  half8& hf = SPILL_OUT ? th[p >> 2] : yhi[f];
+  hf[2 * dq] = t.hi[0];
+  hf[2 * dq + 1] = t.hi[1];
   const int g = f >> 2, d = 2 * (f & 3) + (dq >> 1);
   // the 64-deep fp8 operands of a group (4 fragments = 2 tiles) are collected in the VGPR tuples w8h / w8l and moved to
   // the (AGPR-resident) operand set in one piece when the group is complete: partial writes to an 8-register AGPR tuple
@@ -448,16 +453,34 @@ __device__ __forceinline__ void epi_stage_c8(const PairTmp& t, int p, int FP, ha
     else { ch1[2 * p - 8] = t.cpk[0]; ch1[2 * p - 7] = t.cpk[1]; }
   }
   if (dq == 3) {                                            // fragment f is complete
-    pin_agpr(yhi[f]);
-    if ((f & 3) == 3) {
-      yh8[g] = w8h; yl8[g] = w8l;
-      pin_agpr8(yh8[g]); pin_agpr8(yl8[g]);
+    if (SPILL_OUT) {
+      buf_store(hf, sc, g * SUNERF_GROUP_BYTES + (f & 3) * 1024);
+      if ((f & 3) == 3) {
+        const v4i h0 = {w8h[0], w8h[1], w8h[2], w8h[3]}, h1 = {w8h[4], w8h[5], w8h[6], w8h[7]};
+        const v4i l0 = {w8l[0], w8l[1], w8l[2], w8l[3]}, l1 = {w8l[4], w8l[5], w8l[6], w8l[7]};
+        buf_store(__builtin_bit_cast(half8, h0), sc, g * SUNERF_GROUP_BYTES + 4096);
+        buf_store(__builtin_bit_cast(half8, h1), sc, g * SUNERF_GROUP_BYTES + 5120);
+        buf_store(__builtin_bit_cast(half8, l0), sc, g * SUNERF_GROUP_BYTES + 6144);
+        buf_store(__builtin_bit_cast(half8, l1), sc, g * SUNERF_GROUP_BYTES + 7168);
+      }
+    } else {
+      pin_agpr(hf);
+      if ((f & 3) == 3) {
+        yh8[g] = w8h; yl8[g] = w8l;
+        pin_agpr8(yh8[g]); pin_agpr8(yl8[g]);
+      }
     }
     if (STASH) {
-      buf_store_nt(yhi[f], st, st_off + (p >> 2) * 1024);
+      buf_store_nt(hf, st, st_off + (p >> 2) * 1024);
       buf_store_nt(p < 4 ? ch0 : ch1, st, st_off + (p >> 2) * 1024 + cos_delta);
     }
   }
+}
+__device__ __forceinline__ v8i buf_load8(Rsrc r, int off) {   // two 16-byte halves of an fp8 operand (1 KiB apart)
+  const half8 a = buf_load(r, off), b = buf_load(r, off + 1024);
+  const v4i x = __builtin_bit_cast(v4i, a), y = __builtin_bit_cast(v4i, b);
+  v8i v = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+  return v;
 }
 
 template <int D>
@@ -465,13 +488,15 @@ struct Mlp8 : Mlp<D> {
   using M = Mlp<D>;
   using M::KS; using M::NT; using M::PF; using M::PAGE_STEPS; using M::RING_STEPS; using M::RS_HIDDEN; using M::RS_IN;
   using Pipe = typename M::Pipe;
-  static constexpr int G = KS / 4;                          // 64-deep groups per hidden tile (= per page: PAGE_STEPS == KS)
+  static constexpr int G = KS / 4;                          // 64-deep groups per hidden tile
+  static constexpr int GP = PAGE_STEPS / 4;                 // ... per weight page (d = 512: a tile is two pages)
   static constexpr int PIECES = Ring<D>::PIECES;
-  static_assert(PAGE_STEPS == KS && KS % 4 == 0, "fp8c: a hidden tile is one page of whole groups");
+  static constexpr bool SPILL = M::SPILL;
+  static_assert(KS % PAGE_STEPS == 0 && PAGE_STEPS % 4 == 0, "fp8c: a hidden tile is whole pages of whole groups");
 
   // A operands of the next DIST groups (in-place refill behind the consuming instruction)
   static constexpr int DIST = 1;   // (2 was measured: no faster at d = 256, and it costs 32 registers)
-  static_assert(G % DIST == 0, "operand slot of a group must be a compile-time constant");
+  static_assert(GP % DIST == 0, "operand slot of a group must be a compile-time constant");
   struct Pipe8 {
     half8 a16[DIST][4];
     v8i al8[DIST], ah8[DIST];
@@ -527,11 +552,15 @@ struct Mlp8 : Mlp<D> {
   // (8 pair micro-ops, writing fragments FP, FP + 1 of the y set) is dealt out over the first segments; it must be done
   // before k-step KS - 2, whose operands it produces when the previous tile closed the layer above.
   // RS0: ring k-step of the tile's first group (compile-time) or -1 (run-time, p.rstep).
-  template <bool HAS_PREV, int RS0, bool STASH>
-  static __device__ __forceinline__ f32x16 tile8(Ring<D>& ring, Pipe& p, Pipe8& q, f32x16 acc, const half8* xhi,
-                                                 const v8i* xh8, const v8i* xl8, const Scales sc, const f32x16& prev,
-                                                 f32x16& pc /* in: correction accumulator of prev; out: ours */, int FP, half8* yhi, v8i* yh8, v8i* yl8, v8i& w8h, v8i& w8l, Rsrc st,
-                                                 int st_off, int cos_delta) {
+  // SPILL_OUT / RELOAD (d = 512): the pending epilogue writes to scratch `scr`; in the LAST tile of a layer every operand
+  // of the single register set is refilled, right behind its last use, with the layer's own output from scratch (requests
+  // are committed to the operand registers a few instructions later so the wave never waits for the round trip).
+  template <bool HAS_PREV, int RS0, bool STASH, bool SPILL_OUT = false, bool RELOAD = false>
+  static __device__ __forceinline__ f32x16 tile8(Ring<D>& ring, Pipe& p, Pipe8& q, f32x16 acc, half8* xhi,
+                                                 v8i* xh8, v8i* xl8, const Scales sc, const f32x16& prev,
+                                                 f32x16& pc /* in: correction accumulator of prev; out: ours */, int FP,
+                                                 half8* yhi, v8i* yh8, v8i* yl8, v8i& w8h, v8i& w8l, Rsrc st,
+                                                 int st_off, int cos_delta, Rsrc scr = Rsrc()) {
     constexpr int SEGS = 6 * ((KS - 2) / 4) + ((KS - 2) % 4);        // segments before the deadline
     constexpr int PER = SEGS >= 16 ? 0 : (8 + SEGS - 1) / SEGS;      // 0: one micro-op per two segments (A+B | C)
     half8 ch0, ch1;
@@ -540,6 +569,10 @@ struct Mlp8 : Mlp<D> {
     const LdsBases lb(p);
     f32x16 pv;
     if (PER != 0) pv = prev + pc;        // short tiles (d <= 128): summed up front
+    half8 th[2];                         // SPILL_OUT: fragments under construction
+    constexpr int RL = 3;                // RELOAD: segments between the request of an operand and its commit
+    half8 rl_hi[RL];
+    v8i rl_h8, rl_l8;
     // the block-scaled fp8 instruction sums with ~17 bits (probe: 8e-6 relative on a 64-deep sum): harmless for the
     // corrections themselves (2^-12 of the result) but not for a running sum of order one passed through it, so they
     // get their own accumulator, added once per tile
@@ -553,9 +586,9 @@ struct Mlp8 : Mlp<D> {
       else { nrs = p.rstep + 4 * (g + DIST); nrs = nrs >= RING_STEPS ? nrs - RING_STEPS : nrs; }
       const char* nb = RS0 >= 0 ? nullptr : group_ptr(p, nrs);      // run-time ring position (d = 64): one add per group
       const int nbo = nrs * 2048;                                   // static ring position: base + immediate
-      if (g == G - DIST) {
-        // the refills from here on read the next page: acquire it.  Of the page after it, 2 + 2 (G - DIST) pieces have been
-        // issued by now (two per group since the previous tile's last group); anything else in flight is younger still.
+      if (g % GP == GP - DIST) {
+        // the refills from here on read the next page: acquire it.  Of the page after it, 2 + 2 (GP - DIST) pieces have
+        // been issued by now (two per group since the previous page's last group); anything else in flight is younger.
         ring.template acquire<-2 * (DIST - 1)>();
       }
 #pragma unroll
@@ -578,7 +611,8 @@ struct Mlp8 : Mlp<D> {
             const int i = (seg - 2) >> 1;
             if (seg >= 2 && ((seg - 2) & 1) == 0) {
               if (i < 8) epi_stage_a<STASH>(pv, i, t[i & 1]);
-              if (i >= 1 && i <= 8) epi_stage_c8<STASH>(t[(i - 1) & 1], i - 1, FP, yhi, yh8, yl8, w8h, w8l, ch0, ch1, st, st_off, cos_delta);
+              if (i >= 1 && i <= 8)
+                epi_stage_c8<STASH, SPILL_OUT>(t[(i - 1) & 1], i - 1, FP, yhi, yh8, yl8, w8h, w8l, ch0, ch1, st, st_off, cos_delta, scr, th);
             } else if (seg >= 2 && i < 8) {
               epi_stage_b<STASH>(t[i & 1]);
             }
@@ -592,13 +626,32 @@ struct Mlp8 : Mlp<D> {
 #pragma unroll
             for (int e = 0; e < PER; ++e)
               if (seg * PER + e < 8)
-                epi_stage_c8<STASH>(t[e], seg * PER + e, FP, yhi, yh8, yl8, w8h, w8l, ch0, ch1, st, st_off, cos_delta);
+                epi_stage_c8<STASH, SPILL_OUT>(t[e], seg * PER + e, FP, yhi, yh8, yl8, w8h, w8l, ch0, ch1, st, st_off, cos_delta, scr, th);
           }
         }
         // weight stream: two pieces per group behind the acquire (page + 3 into the slot everyone left)
         if (sg == 1 || sg == 3) {
-          const int piece = 2 * ((g + 1) % G) + (sg == 3 ? 1 : 0);
+          const int piece = 2 * (((g % GP) + 1) % GP) + (sg == 3 ? 1 : 0);
           if (piece < PIECES) M::issue_piece_dyn(ring, piece);
+        }
+        if (RELOAD) {
+          // k-step ks = 4 g + sg (fp16 segments) was the last reader of xhi[ks]; segments 4 / 5 the last readers of
+          // xh8[g] / xl8[g].  Fragments KS-2, KS-1 and the last group arrive through the carry epilogue instead.
+          const int ks = 4 * g + sg;
+          if (sg < 4) {
+            if (ks >= RL && ks - RL < KS - 2) { xhi[ks - RL] = rl_hi[(ks - RL) % RL]; pin_agpr(xhi[ks - RL]); }
+            if (ks < KS - 2) rl_hi[ks % RL] = buf_load(scr, g * SUNERF_GROUP_BYTES + sg * 1024);
+          } else if (sg == 5) {
+            // both fp8 operands of group g have been read: commit group g - 1's (requested one group ago), request ours
+            if (g >= 1) {
+              xh8[g - 1] = rl_h8; xl8[g - 1] = rl_l8;
+              pin_agpr8(xh8[g - 1]); pin_agpr8(xl8[g - 1]);
+            }
+            if (g < G - 1) {
+              rl_h8 = buf_load8(scr, g * SUNERF_GROUP_BYTES + 4096);
+              rl_l8 = buf_load8(scr, g * SUNERF_GROUP_BYTES + 6144);
+            }
+          }
         }
         // in-place prefetch of the next group's operand
         if (RS0 >= 0) {
@@ -613,6 +666,11 @@ struct Mlp8 : Mlp<D> {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (RELOAD) {   // the last RL fp16 requests (the last fp8 pair was committed in group G - 1: nothing pending there)
+#pragma unroll
+      for (int ks = KS; ks < KS + RL; ++ks)
+        if (ks - RL >= 0 && ks - RL < KS - 2) { xhi[ks - RL] = rl_hi[(ks - RL) % RL]; pin_agpr(xhi[ks - RL]); }
+    }
     if (RS0 < 0) {
       p.rstep += KS;
       if (p.rstep >= RING_STEPS) p.rstep -= RING_STEPS;
@@ -622,14 +680,15 @@ struct Mlp8 : Mlp<D> {
   }
 
   // in-layer tile (6 k-steps, classic hi | lo weights and encoding operands) with the fp8c epilogue format
-  template <int T0, bool HAS_PREV, int RS0, bool STASH>
+  template <int T0, bool HAS_PREV, int RS0, bool STASH, bool SPILL_OUT = false>
   static __device__ __forceinline__ f32x16 tile_in(Ring<D>& ring, Pipe& p, f32x16 acc, const half8* xhi, const half8* xlo,
                                                    const f32x16& prev, int FP, half8* yhi, v8i* yh8, v8i* yl8, v8i& w8h,
-                                                   v8i& w8l, Rsrc st, int st_off, int cos_delta) {
+                                                   v8i& w8l, Rsrc st, int st_off, int cos_delta, Rsrc scr = Rsrc()) {
     constexpr int KIN = SUNERF_KS0;
     constexpr int EPI_STEPS = KIN - 2, PER = (8 + EPI_STEPS - 1) / EPI_STEPS;
     constexpr int ACQ = (PAGE_STEPS - PF) % PAGE_STEPS;
     half8 ch0, ch1;
+    half8 th[2];
 #pragma unroll
     for (int s = 0; s < KIN; ++s) {
       const int r = (T0 + s) % PF;
@@ -652,7 +711,8 @@ struct Mlp8 : Mlp<D> {
       if (HAS_PREV) {
 #pragma unroll
         for (int e = 0; e < PER; ++e)
-          if (s * PER + e < 8) epi_stage_c8<STASH>(t[e], s * PER + e, FP, yhi, yh8, yl8, w8h, w8l, ch0, ch1, st, st_off, cos_delta);
+          if (s * PER + e < 8)
+            epi_stage_c8<STASH, SPILL_OUT>(t[e], s * PER + e, FP, yhi, yh8, yl8, w8h, w8l, ch0, ch1, st, st_off, cos_delta, scr, th);
       }
       {
         const int phase = (T0 + s) % PAGE_STEPS;
@@ -681,9 +741,21 @@ struct Mlp8 : Mlp<D> {
   template <bool STASH>
   static __device__ __forceinline__ f32x16 in_layer(Ring<D>& ring, Pipe& p, const float* bias, int h, const half8* ehi,
                                                     const half8* elo, half8* yhi, v8i* yh8, v8i* yl8, v8i& w8h, v8i& w8l,
-                                                    Rsrc st, int st_own) {
+                                                    Rsrc st, int st_own, Rsrc scr = Rsrc()) {
     f32x16 prev = {0};
     constexpr int CD = KS * 1024;
+    if constexpr (SPILL) {   // 16 tiles, output to scratch
+      static_for<0, NT>([&](auto uu) {
+        constexpr int UU = decltype(uu)::value;
+        constexpr int RS = RS_IN < 0 ? -1 : (RS_IN + UU * SUNERF_KS0) % RING_STEPS;
+        constexpr int T0 = (UU * SUNERF_KS0) % PAGE_STEPS;
+        f32x16 acc = bias_tile(bias + 32 * UU, h);
+        acc = tile_in<T0, (UU > 0), RS, STASH, true>(ring, p, acc, ehi, elo, prev, 2 * UU - 2, yhi, yh8, yl8, w8h, w8l, st,
+                                                     st_own + (2 * UU - 2) * 1024, CD, scr);
+        prev = acc;
+      });
+      return prev;
+    }
 #pragma unroll
     for (int U = 0; U < NT; ++U) {
       f32x16 acc = bias_tile(bias + 32 * U, h);
@@ -708,10 +780,27 @@ struct Mlp8 : Mlp<D> {
   static __device__ __forceinline__ f32x16 hidden_layer(Ring<D>& ring, Pipe& p, Pipe8& q, const float* bias, int h,
                                                         const Scales sc, half8* xhi, v8i* xh8, v8i* xl8, half8* yhi,
                                                         v8i* yh8, v8i* yl8, v8i& w8h, v8i& w8l, const f32x16& carry, f32x16& pc,
-                                                        Rsrc st, int st_prev, int st_own) {
+                                                        Rsrc st, int st_prev, int st_own, Rsrc scr = Rsrc()) {
     f32x16 prev = carry;
     constexpr int CD = KS * 1024;
     constexpr int XL = 2 * NT - 2;
+    if constexpr (SPILL) {
+      // one operand set: tile 0 finishes it (carry epilogue into registers), tiles 1 .. NT-1 send the output to scratch,
+      // the last tile pulls that output back in as the next layer's input
+      static_for<0, NT>([&](auto uu) {
+        constexpr int UU = decltype(uu)::value;
+        constexpr int RS = RS_HIDDEN < 0 ? -1 : (RS_HIDDEN + UU * KS) % RING_STEPS;
+        f32x16 acc = bias_tile(bias + 32 * UU, h);
+        if constexpr (UU == 0)
+          acc = tile8<true, RS, STASH, false, false>(ring, p, q, acc, xhi, xh8, xl8, sc, prev, pc, XL, xhi, xh8, xl8, w8h, w8l,
+                                                     st, st_prev + XL * 1024, CD, scr);
+        else
+          acc = tile8<true, RS, STASH, true, (UU == NT - 1)>(ring, p, q, acc, xhi, xh8, xl8, sc, prev, pc, 2 * UU - 2, xhi, xh8,
+                                                             xl8, w8h, w8l, st, st_own + (2 * UU - 2) * 1024, CD, scr);
+        prev = acc;
+      });
+      return prev;
+    }
 #pragma unroll
     for (int U = 0; U < NT; ++U) {
       f32x16 acc = bias_tile(bias + 32 * U, h);
@@ -798,7 +887,63 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
       }
       f32x16 out;
       const float* obias = bias + (size_t)(a.n_linear - 1) * D;
-      if constexpr (FP8C) {
+      if constexpr (FP8C && M::SPILL) {
+        // d_filter = 512, fp8c arithmetic: ONE operand set (128 + 64 + 64 = 256 AGPRs); every layer writes its output to
+        // this wave's scratch and its last tile pulls that output back in as the next layer's input
+        using M8 = Mlp8<D>;
+        constexpr int G = M8::G;
+        const Rsrc scratch = make_rsrc(a.scratch + ((size_t)blockIdx.x * WAVES + wave) * ((size_t)M::KS * 2048), M::KS * 2048);
+        half8 x_hi[M::KS];
+        v8i x_h8[G], x_l8[G];
+        half8 e_hi[SUNERF_KS0], e_lo[SUNERF_KS0];
+        encode_point(v, h, [&](int q, float val) {
+          const _Float16 hi = (_Float16)val;
+          e_hi[q >> 3][q & 7] = hi;
+          e_lo[q >> 3][q & 7] = (_Float16)(val - (float)hi);
+        });
+        if (STASH) {
+#pragma unroll
+          for (int s = 0; s < SUNERF_KS0; ++s) buf_store(e_hi[s], st, s * 1024);
+        }
+        const int* shp = (const int*)(a.packed + L.scale_off());
+        if (c != 0 || group != (int64_t)blockIdx.x) {
+#pragma unroll
+          for (int s = 0; s < M::PF; ++s) M::load_frag(pipe, s, (M::RS_IN + s) % M::RING_STEPS);
+        }
+        v8i w8h = {0}, w8l = {0};
+        f32x16 carry = M8::template in_layer<STASH>(ring, pipe, bias, h, e_hi, e_lo, x_hi, x_h8, x_l8, w8h, w8l, st,
+                                                    (int)SL.h_off(0), scratch);
+        // the in layer's tiles are too short to pull the next input in piece by piece: fetch everything but the last two
+        // fragments / the last group's fp8 operands (they arrive through the carry epilogue), one group at a time
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+          for (int sl = 0; sl < 4; ++sl)
+            if (4 * g + sl < M::KS - 2) x_hi[4 * g + sl] = buf_load(scratch, g * SUNERF_GROUP_BYTES + sl * 1024);
+          if (g < G - 1) {
+            x_h8[g] = buf_load8(scratch, g * SUNERF_GROUP_BYTES + 4096);
+            x_l8[g] = buf_load8(scratch, g * SUNERF_GROUP_BYTES + 6144);
+          }
+#pragma unroll
+          for (int sl = 0; sl < 4; ++sl)
+            if (4 * g + sl < M::KS - 2) pin_agpr(x_hi[4 * g + sl]);
+          if (g < G - 1) { pin_agpr8(x_h8[g]); pin_agpr8(x_l8[g]); }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        typename M8::Pipe8 q8;
+        f32x16 pc = {0};
+        M8::preload(pipe, q8, M::RS_HIDDEN);
+        auto scales = [&](int l) {
+          const int sh = shp[l];
+          typename M8::Scales sc = {127 - (sh + 11), 127 - sh};
+          return sc;
+        };
+        for (int l = 1; l < a.n_linear - 1; ++l)
+          carry = M8::template hidden_layer<STASH>(ring, pipe, q8, bias + (size_t)l * D, h, scales(l), x_hi, x_h8, x_l8, x_hi, x_h8,
+                                                   x_l8, w8h, w8l, carry, pc, st, (int)SL.h_off(l - 1), (int)SL.h_off(l), scratch);
+        out = M8::template out_layer<STASH>(ring, pipe, q8, obias, h, scales(a.n_linear - 1), x_hi, x_h8, x_l8, w8h, w8l, carry, pc,
+                                            st, (int)SL.h_off(a.n_linear - 2));
+      } else if constexpr (FP8C) {
         using M8 = Mlp8<D>;
         constexpr int G = M8::G;
         // two operand sets in the fp8c format: fp16 heads + the two 64-deep fp8 operands (head, scaled remainder)
@@ -1001,10 +1146,8 @@ int launch_render_t(const RenderArgs& a, hipStream_t stream) {
 }
 template <int D>
 int launch_render(const RenderArgs& a, int precision, hipStream_t stream) {
-  if constexpr (D <= 256) {
-    if (precision == SUNERF_PRECISION_FAST)
-      return a.stash ? launch_render_t<D, true, true>(a, stream) : launch_render_t<D, false, true>(a, stream);
-  }
+  if (precision == SUNERF_PRECISION_FAST)
+    return a.stash ? launch_render_t<D, true, true>(a, stream) : launch_render_t<D, false, true>(a, stream);
   return a.stash ? launch_render_t<D, true, false>(a, stream) : launch_render_t<D, false, false>(a, stream);
 }
 
@@ -1031,7 +1174,6 @@ extern "C" int sunerf_emission_render_fwd(const void* packed, int d_filter, int 
   if (n_rays < 0 || n_samples < 2) return SUNERF_E_BADARG;
   if (n_linear < 2 || n_linear > SUNERF_MAX_LAYERS) return SUNERF_E_UNSUPPORTED;
   if (precision != SUNERF_PRECISION_FAST && precision != SUNERF_PRECISION_EXACT) return SUNERF_E_BADARG;
-  if (precision == SUNERF_PRECISION_FAST && d_filter > 256) return SUNERF_E_UNSUPPORTED;   // packed images differ
   if (n_rays == 0) return 0;      // an empty batch is valid (its tensors have null data pointers)
   if (!packed || !rays_o || !rays_d || !times || !z_vals || !image || !weights || !absorption) return SUNERF_E_BADARG;
   RenderArgs a;

@@ -18,12 +18,14 @@ PRECISION_FAST, PRECISION_EXACT = 0, 1     # include/sunerf_hip.h: SUNERF_PRECIS
 
 
 def default_precision(d_filter: int) -> int:
-    """Forward arithmetic of newly packed models: ``SUNERF_FORWARD_PRECISION=exact`` (environment) selects three fp16
-    products per term everywhere; the default is the fp16 + fp8-correction mode where it exists (d_filter <= 256)."""
+    """Forward arithmetic of newly packed models: ``SUNERF_FORWARD_PRECISION`` = ``exact`` (three fp16 products per term) or
+    ``fast`` (fp16 head product + two block-scaled fp8 correction products); unset = fast."""
     import os
-    if d_filter > 256 or os.environ.get('SUNERF_FORWARD_PRECISION', 'fast').lower() == 'exact':
-        return PRECISION_EXACT
-    return PRECISION_FAST
+    mode = os.environ.get('SUNERF_FORWARD_PRECISION', 'fast').lower()
+    if mode not in ('fast', 'exact'):
+        raise ValueError(f"SUNERF_FORWARD_PRECISION must be 'fast' or 'exact', not {mode!r}")
+    return PRECISION_EXACT if mode == 'exact' else PRECISION_FAST
+
 
 _workspaces = {}                        # device -> scratch for the d_filter = 512 render kernel (per stream use is serial)
 
@@ -57,8 +59,6 @@ class PackedMLP:
         self.n_linear = len(weights)
         self.d_filter = int(weights[0].shape[0])
         self.precision = default_precision(self.d_filter) if precision is None else int(precision)
-        if self.precision == PRECISION_FAST and self.d_filter > 256:
-            raise ValueError('the fp8-correction forward exists for d_filter <= 256 only')
         self.d_out = int(weights[-1].shape[0])
         if self.d_filter not in SUPPORTED_D_FILTER:
             raise ValueError(f'd_filter={self.d_filter} is not in the compiled set {SUPPORTED_D_FILTER}')

@@ -56,13 +56,19 @@ def test_render_pass_backward(ops, d_filter, n_layers, S, precision):
     fwd = ops.emission_render_fwd(packed, o.to(dev), d.to(dev), t.to(dev), z.to(dev), reg_radius=1.2, want_epilogues=True,
                                   training=True)
     # the training variant of the kernel must produce the same forward results
-    assert ((fwd['image'].cpu() - ref_out['image']).abs().max() / ref_out['image'].abs().max()).item() < 1e-4
+    # image = sum exp(r0) ...: its relative error is the ABSOLUTE error of the raw output r0.  EXACT arithmetic keeps that
+    # ~1e-7 |r0|; the fp8-correction arithmetic has rms ~1e-5 |r0| and a 4-sigma tail of ~4e-5 |r0| over the ~1e3 samples
+    # here -- inside 1e-4 for |r0| up to ~2.5; this parametrisation (last layer scaled x4) reaches |r0| = 3.8 at d=512
+    raw_scale = ref_out['raw'].abs().max().item()
+    tol = 1e-4 if precision == 'exact' else max(1e-4, 5e-5 * raw_scale)
+    assert ((fwd['image'].cpu() - ref_out['image']).abs().max() / ref_out['image'].abs().max()).item() < tol
     gW = [torch.full_like(W, float('nan')) for W in Ws]
     gb = [torch.full_like(b, float('nan')) for b in bs]
     g_raw = ops.emission_render_bwd(packed, o.to(dev), d.to(dev), z.to(dev), fwd['raw'], fwd['stash'], g_image.to(dev), None,
                                     g_reg_const, 1.2, gW, gb)
     torch.cuda.synchronize()
-    assert (g_raw.cpu() - ref_graw).abs().max().item() <= 1e-4 * ref_graw.abs().max().item()
+    # g_raw ~ exp(r0) x (fp32 integral terms): it inherits the forward's absolute error on r0, hence the same bound
+    assert (g_raw.cpu() - ref_graw).abs().max().item() <= tol * ref_graw.abs().max().item()
     for i, ((rW, rb), W, b) in enumerate(zip(ref_grads, gW, gb)):
         assert torch.isfinite(W).all() and torch.isfinite(b).all(), i
         eW = ((W.cpu() - rW).norm() / rW.norm()).item()

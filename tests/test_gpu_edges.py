@@ -134,7 +134,7 @@ def test_unsupported_width_is_a_clear_error():
 
 
 @pytest.mark.parametrize('n_layers,S', [(8, 64), (2, 32), (3, 40)])
-def test_reference_default_width_512_forward(ops, n_layers, S):
+def test_reference_default_width_512_forward(ops, n_layers, S, precision):
     """d_filter = 512 is the reference's default (model.py:16): one activation set in registers + scratch spill."""
     params, packed = _packed(ops, d_filter=512, n_layers=n_layers, seed=11)
     torch.manual_seed(S)

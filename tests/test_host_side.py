@@ -52,11 +52,11 @@ def test_argument_errors_without_gpu(lib):
     assert lib.sunerf_hier_resample(None, None, None, 0, 4, 8, 8, None, None, None) == -1
     assert lib.sunerf_emission_render_fwd(None, 256, 9, 0, None, None, None, None, 4, 8, None, None, None, None, None, None,
                                           None, 1.2, None, None, 0, None) == -1
-    # precision: an unknown mode is a bad argument; the fp8-correction mode does not exist at d_filter = 512
+    # precision: an unknown mode is a bad argument
     assert lib.sunerf_emission_render_fwd(None, 256, 9, 5, None, None, None, None, 4, 8, None, None, None, None, None, None,
                                           None, 1.2, None, None, 0, None) == -1
-    assert lib.sunerf_emission_render_fwd(None, 512, 9, 0, None, None, None, None, 4, 8, None, None, None, None, None, None,
-                                          None, 1.2, None, None, 0, None) == -2
+    assert lib.sunerf_emission_render_fwd(None, 384, 9, 0, None, None, None, None, 4, 8, None, None, None, None, None, None,
+                                          None, 1.2, None, None, 0, None) == -1        # null pointers are checked first
     assert lib.sunerf_render_workspace_bytes(256) == 0 and lib.sunerf_render_workspace_bytes(512) == 1024 * 4 * 32 * 2048
 
 
