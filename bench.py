@@ -170,9 +170,11 @@ def main():
     ap.add_argument('--no-two-pass', action='store_true', help='skip the reference-shaped two-pass figure (train mode)')
     ap.add_argument('--dt', action='store_true', help='also time BASELINE config 5: density-temperature head, two-pass, '
                                                       '256 samples per ray in the fine pass (reported under "dt_two_pass")')
-    ap.add_argument('--d-filter', type=int, default=D_FILTER, help='MLP width (headline: 256; 512 = reference default, fwd only)')
+    ap.add_argument('--d-filter', type=int, default=D_FILTER, help='MLP width (headline: 256; 512 = reference default)')
     args = ap.parse_args()
     globals()['D_FILTER'] = args.d_filter
+    fast = os.environ.get('SUNERF_FORWARD_PRECISION', 'fast').lower() != 'exact'
+    FP8C = 'true' if fast else 'false'
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -216,7 +218,7 @@ def main():
 
         def step(i):
             return ops.emission_render_fwd(packed, rays_o, rays_d, times, z_vals, reg_radius=1.2, want_epilogues=True)['image']
-        flops_per_sample, kernel_name = flops_fwd(D_FILTER), f'render_fwd_kernel<{D_FILTER}, false>'
+        flops_per_sample, kernel_name = flops_fwd(D_FILTER), f'render_fwd_kernel<{D_FILTER}, false, {FP8C}>'
     else:
         # this rank's rows of the frame; batches of --batch rays cycle through them
         r0, r1 = shard_range(args.res, rank, world)
@@ -245,7 +247,7 @@ def main():
             loss.backward()
             opt.step(skip_if_positive=stats[5:6])
             return loss
-        flops_per_sample, kernel_name = flops_fwd(D_FILTER) + flops_bwd(D_FILTER), f'render_fwd_kernel<{D_FILTER}, true> + dgrad + wgrad'
+        flops_per_sample, kernel_name = flops_fwd(D_FILTER) + flops_bwd(D_FILTER), f'render_fwd_kernel<{D_FILTER}, true, {FP8C}> + dgrad + wgrad'
 
     for i in range(args.warmup):
         step(i)
@@ -280,7 +282,6 @@ def main():
         achieved = rays_per_step * args.samples * flops_per_sample / (step_ms * 1e-3) / 1e12
         # matrix-pipe work of the forward per algorithmic flop: EXACT 3 fp16 products; FAST 1 fp16 product + two 64-deep
         # fp8 instructions per four 16-deep steps (measured 84 cycles each against 4 x 32: tools/probes/bench_mfma_mix.hip)
-        fast = D_FILTER <= 256 and os.environ.get('SUNERF_FORWARD_PRECISION', 'fast').lower() != 'exact'
         fwd_factor = 1.0 + 2.0 * 84.0 / 128.0 if fast else 3.0
         if args.mode == 'fwd':
             executed_factor = fwd_factor
@@ -302,9 +303,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': ('f32 (forward: every operand split into an fp16 head and an exact remainder, head products on the fp16 '
-                      'matrix cores + ' + ('block-scaled fp8 products for the two cross terms' if D_FILTER <= 256 and
-                                           os.environ.get('SUNERF_FORWARD_PRECISION', 'fast').lower() != 'exact'
-                                           else 'fp16 products for the two cross terms')
+                      'matrix cores + ' + ('block-scaled fp8 products for the two cross terms' if fast else 'fp16 products for the two cross terms')
                       + '; backward: fp16 MFMA, W^T hi + lo; fp32 accumulate and parameters)'),
             'data': 'synthetic',
             'config': {'workload': (f'emission render {what}, {args.res}x{args.res} frame x {args.samples} samples/ray, '

@@ -38,10 +38,10 @@ extern "C" {
 
 /* forward arithmetic of the MLP products x*w (x, w split into fp16 head + exact fp32 remainder); the packed image and the
  * render call must name the same mode.
- *   FAST  (d_filter <= 256): head*head on the fp16 matrix cores + the two cross terms as block-scaled fp8 products
- *         (v_mfma_scale_f32_32x32x64_f8f6f4); raw MLP output within ~1e-5 abs of fp32 (images ~1e-5 rel: the 1e-4 parity
- *         gate with a decade to spare), 18 % faster than EXACT at d_filter = 256
- *   EXACT : all three terms as fp16 products (fp32-class results, raw within ~1e-7); the only mode at d_filter = 512 */
+ *   FAST  : head*head on the fp16 matrix cores + the two cross terms as block-scaled fp8 products
+ *           (v_mfma_scale_f32_32x32x64_f8f6f4); raw MLP output within ~1e-5 |raw| rms (4e-5 |raw| worst sample) of fp32,
+ *           i.e. images ~1e-5 rel for |raw| ~ 1: inside the 1e-4 parity gate; 18 % (d_filter 256) / 23 % (512) faster
+ *   EXACT : all three terms as fp16 products (fp32-class results, raw within ~1e-7) */
 #define SUNERF_PRECISION_FAST  0
 #define SUNERF_PRECISION_EXACT 1
 
