@@ -412,6 +412,12 @@ struct Mlp {
   }
 };
 
+#ifndef SUNERF_PIN_MFMA
+#define SUNERF_PIN_MFMA 1
+#endif
+#ifndef SUNERF_BATCH_READS
+#define SUNERF_BATCH_READS 1
+#endif
 // ---- d <= 256: fp16 head product + two block-scaled fp8 correction products (format: sunerf_common.h, "fp8c") ----------
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -601,6 +607,11 @@ struct Mlp8 : Mlp<D> {
         } else {
           accc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(q.ah8[slot8], xl8[g], accc, 0, 0, 0, sc.a_hi, 0, 127 - 11);
         }
+#if SUNERF_PIN_MFMA
+        // the matrix instruction opens its segment: what follows runs in ITS shadow (without this the scheduler is free to
+        // move it to the end of the segment, i.e. behind work that was sized for the previous instruction)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if (HAS_PREV) {
           if (PER == 0) {
             // The previous tile's two accumulators are summed in segment 2, behind two of this tile's matrix instructions
@@ -655,9 +666,22 @@ struct Mlp8 : Mlp<D> {
         }
         // in-place prefetch of the next group's operand
         if (RS0 >= 0) {
+#if SUNERF_BATCH_READS
+          // all reads of the next group behind the two long (84-cycle) fp8 instructions: the four fp16 operands after the
+          // first, the two fp8 operands after the second.  One s_waitcnt per batch instead of one per matrix instruction,
+          // and the 32-cycle fp16 segments keep their few issue slots for the epilogue.
+          if (sg == 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q.a16[slot8][i] = lds_half8(lb.at(nbo + i * 1024));
+          } else if (sg == 5) {
+            q.al8[slot8] = lds_v8i(lb.at(nbo + 4096), lb.at(nbo + 5120));
+            q.ah8[slot8] = lds_v8i(lb.at(nbo + 6144), lb.at(nbo + 7168));
+          }
+#else
           if (sg < 4) q.a16[slot8][sg] = lds_half8(lb.at(nbo + sg * 1024));
           else if (sg == 4) q.al8[slot8] = lds_v8i(lb.at(nbo + 4096), lb.at(nbo + 5120));
           else q.ah8[slot8] = lds_v8i(lb.at(nbo + 6144), lb.at(nbo + 7168));
+#endif
         } else {
           if (sg < 4) q.a16[slot8][sg] = *(const half8*)(nb + sg * 1024);
           else if (sg == 4) q.al8[slot8] = load8(nb + 4096);
