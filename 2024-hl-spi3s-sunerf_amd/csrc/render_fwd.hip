@@ -426,8 +426,8 @@ __device__ __forceinline__ void pin_agpr8(v8i& f) { asm volatile("" : "+a"(f)); 
 // Stage C of a pair micro-op, fp8c operand format: the finished values go into fragment FP + (p >> 2) of the output set as
 // fp16 head (yhi) and as two fp8 words -- the head itself and the remainder scaled by 2^11 -- of the 64-deep fp8 operands
 // (group = fragment / 4; dword 2 (fragment % 4) + (p % 4) / 2, 16-bit word (p % 4) % 2).
-// SPILL_OUT (d = 512, one operand set): the finished fragment / group goes to this wave's scratch instead of registers --
-// per group 8 KiB: [4 x 1 KiB fp16 heads][2 x 1 KiB fp8 heads][2 x 1 KiB fp8 remainders] (the weight stream's arrangement);
+// SPILL_OUT (d = 512: one set of fp16 heads, two sets of fp8 operands): the finished fp16 fragment goes to this wave's
+// scratch (1 KiB per fragment, fragment order) instead of registers, the fp8 group stays in registers like at d <= 256;
 // `th` collects the fragment under construction.
 template <bool STASH, bool SPILL_OUT = false>
 __device__ __forceinline__ void epi_stage_c8(const PairTmp& t, int p, int FP, half8* yhi, v8i* yh8, v8i* yl8, v8i& w8h,
@@ -460,14 +460,10 @@ __device__ __forceinline__ void epi_stage_c8(const PairTmp& t, int p, int FP, ha
   }
   if (dq == 3) {                                            // fragment f is complete
     if (SPILL_OUT) {
-      buf_store(hf, sc, g * SUNERF_GROUP_BYTES + (f & 3) * 1024);
+      buf_store(hf, sc, f * 1024);
       if ((f & 3) == 3) {
-        const v4i h0 = {w8h[0], w8h[1], w8h[2], w8h[3]}, h1 = {w8h[4], w8h[5], w8h[6], w8h[7]};
-        const v4i l0 = {w8l[0], w8l[1], w8l[2], w8l[3]}, l1 = {w8l[4], w8l[5], w8l[6], w8l[7]};
-        buf_store(__builtin_bit_cast(half8, h0), sc, g * SUNERF_GROUP_BYTES + 4096);
-        buf_store(__builtin_bit_cast(half8, h1), sc, g * SUNERF_GROUP_BYTES + 5120);
-        buf_store(__builtin_bit_cast(half8, l0), sc, g * SUNERF_GROUP_BYTES + 6144);
-        buf_store(__builtin_bit_cast(half8, l1), sc, g * SUNERF_GROUP_BYTES + 7168);
+        yh8[g] = w8h; yl8[g] = w8l;
+        pin_agpr8(yh8[g]); pin_agpr8(yl8[g]);
       }
     } else {
       pin_agpr(hf);
@@ -578,7 +574,6 @@ struct Mlp8 : Mlp<D> {
     half8 th[2];                         // SPILL_OUT: fragments under construction
     constexpr int RL = 3;                // RELOAD: segments between the request of an operand and its commit
     half8 rl_hi[RL];
-    v8i rl_h8, rl_l8;
     // the block-scaled fp8 instruction sums with ~17 bits (probe: 8e-6 relative on a 64-deep sum): harmless for the
     // corrections themselves (2^-12 of the result) but not for a running sum of order one passed through it, so they
     // get their own accumulator, added once per tile
@@ -646,22 +641,12 @@ struct Mlp8 : Mlp<D> {
           if (piece < PIECES) M::issue_piece_dyn(ring, piece);
         }
         if (RELOAD) {
-          // k-step ks = 4 g + sg (fp16 segments) was the last reader of xhi[ks]; segments 4 / 5 the last readers of
-          // xh8[g] / xl8[g].  Fragments KS-2, KS-1 and the last group arrive through the carry epilogue instead.
+          // k-step ks = 4 g + sg (fp16 segments) was the last reader of xhi[ks].  Fragments KS-2, KS-1 arrive through the
+          // carry epilogue instead; the fp8 operands of the next layer are the other register set (nothing to reload).
           const int ks = 4 * g + sg;
           if (sg < 4) {
             if (ks >= RL && ks - RL < KS - 2) { xhi[ks - RL] = rl_hi[(ks - RL) % RL]; pin_agpr(xhi[ks - RL]); }
-            if (ks < KS - 2) rl_hi[ks % RL] = buf_load(scr, g * SUNERF_GROUP_BYTES + sg * 1024);
-          } else if (sg == 5) {
-            // both fp8 operands of group g have been read: commit group g - 1's (requested one group ago), request ours
-            if (g >= 1) {
-              xh8[g - 1] = rl_h8; xl8[g - 1] = rl_l8;
-              pin_agpr8(xh8[g - 1]); pin_agpr8(xl8[g - 1]);
-            }
-            if (g < G - 1) {
-              rl_h8 = buf_load8(scr, g * SUNERF_GROUP_BYTES + 4096);
-              rl_l8 = buf_load8(scr, g * SUNERF_GROUP_BYTES + 6144);
-            }
+            if (ks < KS - 2) rl_hi[ks % RL] = buf_load(scr, ks * 1024);
           }
         }
         // in-place prefetch of the next group's operand
@@ -690,7 +675,7 @@ struct Mlp8 : Mlp<D> {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (RELOAD) {   // the last RL fp16 requests (the last fp8 pair was committed in group G - 1: nothing pending there)
+    if (RELOAD) {   // the last RL fp16 requests
 #pragma unroll
       for (int ks = KS; ks < KS + RL; ++ks)
         if (ks - RL >= 0 && ks - RL < KS - 2) { xhi[ks - RL] = rl_hi[(ks - RL) % RL]; pin_agpr(xhi[ks - RL]); }
@@ -809,8 +794,9 @@ struct Mlp8 : Mlp<D> {
     constexpr int CD = KS * 1024;
     constexpr int XL = 2 * NT - 2;
     if constexpr (SPILL) {
-      // one operand set: tile 0 finishes it (carry epilogue into registers), tiles 1 .. NT-1 send the output to scratch,
-      // the last tile pulls that output back in as the next layer's input
+      // one set of fp16 heads: tile 0 finishes it (carry epilogue into registers), tiles 1 .. NT-1 send their fp16 output
+      // to scratch, the last tile pulls it back in as the next layer's input; the fp8 operands alternate between two
+      // register sets (x8 -> y8), the carry epilogue completes the x8 set in place
       static_for<0, NT>([&](auto uu) {
         constexpr int UU = decltype(uu)::value;
         constexpr int RS = RS_HIDDEN < 0 ? -1 : (RS_HIDDEN + UU * KS) % RING_STEPS;
@@ -819,8 +805,8 @@ struct Mlp8 : Mlp<D> {
           acc = tile8<true, RS, STASH, false, false>(ring, p, q, acc, xhi, xh8, xl8, sc, prev, pc, XL, xhi, xh8, xl8, w8h, w8l,
                                                      st, st_prev + XL * 1024, CD, scr);
         else
-          acc = tile8<true, RS, STASH, true, (UU == NT - 1)>(ring, p, q, acc, xhi, xh8, xl8, sc, prev, pc, 2 * UU - 2, xhi, xh8,
-                                                             xl8, w8h, w8l, st, st_own + (2 * UU - 2) * 1024, CD, scr);
+          acc = tile8<true, RS, STASH, true, (UU == NT - 1)>(ring, p, q, acc, xhi, xh8, xl8, sc, prev, pc, 2 * UU - 2, xhi, yh8,
+                                                             yl8, w8h, w8l, st, st_own + (2 * UU - 2) * 1024, CD, scr);
         prev = acc;
       });
       return prev;
@@ -912,13 +898,16 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
       f32x16 out;
       const float* obias = bias + (size_t)(a.n_linear - 1) * D;
       if constexpr (FP8C && M::SPILL) {
-        // d_filter = 512, fp8c arithmetic: ONE operand set (128 + 64 + 64 = 256 AGPRs); every layer writes its output to
-        // this wave's scratch and its last tile pulls that output back in as the next layer's input
+        // d_filter = 512, fp8c arithmetic: ONE set of fp16 heads (128 AGPRs) -- every layer writes its fp16 output to this
+        // wave's scratch and its last tile pulls it back in as the next layer's input -- and TWO sets of the 64-deep fp8
+        // operands (2 x 64 AGPRs) that alternate as input / output from layer to layer.  (With the fp8 operands in the
+        // scratch as well the wave moved 64 KiB per layer each way; 4 waves x 64 KiB is more than this CU's share of the
+        // XCD's L2, so all of it went over the fabric: 140 GB per 4.19 M samples, measured -- profiles/hbm_traffic_d512.)
         using M8 = Mlp8<D>;
         constexpr int G = M8::G;
         const Rsrc scratch = make_rsrc(a.scratch + ((size_t)blockIdx.x * WAVES + wave) * ((size_t)M::KS * 2048), M::KS * 2048);
         half8 x_hi[M::KS];
-        v8i x_h8[G], x_l8[G];
+        v8i a_h8[G], a_l8[G], b_h8[G], b_l8[G];
         half8 e_hi[SUNERF_KS0], e_lo[SUNERF_KS0];
         encode_point(v, h, [&](int q, float val) {
           const _Float16 hi = (_Float16)val;
@@ -935,23 +924,18 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
           for (int s = 0; s < M::PF; ++s) M::load_frag(pipe, s, (M::RS_IN + s) % M::RING_STEPS);
         }
         v8i w8h = {0}, w8l = {0};
-        f32x16 carry = M8::template in_layer<STASH>(ring, pipe, bias, h, e_hi, e_lo, x_hi, x_h8, x_l8, w8h, w8l, st,
+        f32x16 carry = M8::template in_layer<STASH>(ring, pipe, bias, h, e_hi, e_lo, x_hi, a_h8, a_l8, w8h, w8l, st,
                                                     (int)SL.h_off(0), scratch);
-        // the in layer's tiles are too short to pull the next input in piece by piece: fetch everything but the last two
-        // fragments / the last group's fp8 operands (they arrive through the carry epilogue), one group at a time
+        // the in layer's tiles are too short to pull the next input in piece by piece: fetch all fp16 fragments but the
+        // last two (they arrive through the carry epilogue), one group at a time
 #pragma unroll
         for (int g = 0; g < G; ++g) {
 #pragma unroll
           for (int sl = 0; sl < 4; ++sl)
-            if (4 * g + sl < M::KS - 2) x_hi[4 * g + sl] = buf_load(scratch, g * SUNERF_GROUP_BYTES + sl * 1024);
-          if (g < G - 1) {
-            x_h8[g] = buf_load8(scratch, g * SUNERF_GROUP_BYTES + 4096);
-            x_l8[g] = buf_load8(scratch, g * SUNERF_GROUP_BYTES + 6144);
-          }
+            if (4 * g + sl < M::KS - 2) x_hi[4 * g + sl] = buf_load(scratch, (4 * g + sl) * 1024);
 #pragma unroll
           for (int sl = 0; sl < 4; ++sl)
             if (4 * g + sl < M::KS - 2) pin_agpr(x_hi[4 * g + sl]);
-          if (g < G - 1) { pin_agpr8(x_h8[g]); pin_agpr8(x_l8[g]); }
           __builtin_amdgcn_sched_barrier(0);
         }
         typename M8::Pipe8 q8;
@@ -962,11 +946,23 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
           typename M8::Scales sc = {127 - (sh + 11), 127 - sh};
           return sc;
         };
-        for (int l = 1; l < a.n_linear - 1; ++l)
-          carry = M8::template hidden_layer<STASH>(ring, pipe, q8, bias + (size_t)l * D, h, scales(l), x_hi, x_h8, x_l8, x_hi, x_h8,
-                                                   x_l8, w8h, w8l, carry, pc, st, (int)SL.h_off(l - 1), (int)SL.h_off(l), scratch);
-        out = M8::template out_layer<STASH>(ring, pipe, q8, obias, h, scales(a.n_linear - 1), x_hi, x_h8, x_l8, w8h, w8l, carry, pc,
-                                            st, (int)SL.h_off(a.n_linear - 2));
+        int l = 1;
+        for (; l + 1 < a.n_linear - 1; l += 2) {
+          carry = M8::template hidden_layer<STASH>(ring, pipe, q8, bias + (size_t)l * D, h, scales(l), x_hi, a_h8, a_l8, x_hi, b_h8,
+                                                   b_l8, w8h, w8l, carry, pc, st, (int)SL.h_off(l - 1), (int)SL.h_off(l), scratch);
+          carry = M8::template hidden_layer<STASH>(ring, pipe, q8, bias + (size_t)(l + 1) * D, h, scales(l + 1), x_hi, b_h8, b_l8,
+                                                   x_hi, a_h8, a_l8, w8h, w8l, carry, pc, st, (int)SL.h_off(l), (int)SL.h_off(l + 1),
+                                                   scratch);
+        }
+        if (l < a.n_linear - 1) {
+          carry = M8::template hidden_layer<STASH>(ring, pipe, q8, bias + (size_t)l * D, h, scales(l), x_hi, a_h8, a_l8, x_hi, b_h8,
+                                                   b_l8, w8h, w8l, carry, pc, st, (int)SL.h_off(l - 1), (int)SL.h_off(l), scratch);
+          out = M8::template out_layer<STASH>(ring, pipe, q8, obias, h, scales(a.n_linear - 1), x_hi, b_h8, b_l8, w8h, w8l, carry, pc,
+                                              st, (int)SL.h_off(a.n_linear - 2));
+        } else {
+          out = M8::template out_layer<STASH>(ring, pipe, q8, obias, h, scales(a.n_linear - 1), x_hi, a_h8, a_l8, w8h, w8l, carry, pc,
+                                              st, (int)SL.h_off(a.n_linear - 2));
+        }
       } else if constexpr (FP8C) {
         using M8 = Mlp8<D>;
         constexpr int G = M8::G;
