@@ -245,7 +245,7 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_pair_kernel(DgradArgs a) 
       {
         const int c0 = (int)SL.c_off(n_act - 1);
 #pragma unroll
-        for (int f = 0; f < 2 * CW; ++f) { cw0[f] = buf_load(sb0, c0 + f * 1024); cw1[f] = buf_load(sb1, c0 + f * 1024); }
+        for (int f = 0; f < 2 * CW; ++f) { cw0[f] = buf_load_nt(sb0, c0 + f * 1024); cw1[f] = buf_load_nt(sb1, c0 + f * 1024); }
       }
       // window slot `ws` (a literal) is free again after the epilogue of tile Up of the layer whose cos is lc: it takes tile
       // Up + CW -- of the same layer while Up + CW < NT, else tile Up + CW - NT of the next layer down (clamped to layer 0 at
@@ -255,10 +255,10 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_pair_kernel(DgradArgs a) 
         const int Un = same ? Up + CW : Up + CW - NT;
         const int ln = same ? lc : (lc - 1 >= 0 ? lc - 1 : 0);
         const int off = (int)SL.c_off(ln) + (2 * Un) * 1024;
-        cw0[2 * ws] = buf_load(sb0, off);
-        cw0[2 * ws + 1] = buf_load(sb0, off + 1024);
-        cw1[2 * ws] = buf_load(sb1, off);
-        cw1[2 * ws + 1] = buf_load(sb1, off + 1024);
+        cw0[2 * ws] = buf_load_nt(sb0, off);
+        cw0[2 * ws + 1] = buf_load_nt(sb0, off + 1024);
+        cw1[2 * ws] = buf_load_nt(sb1, off);
+        cw1[2 * ws + 1] = buf_load_nt(sb1, off + 1024);
       };
 
       // pending epilogue: accumulators of the tile just finished; t?? collect the packed dZ fragments

@@ -141,4 +141,7 @@ __device__ __forceinline__ void buf_store_nt(half8 v, Rsrc r, int off) {   // no
 __device__ __forceinline__ half8 buf_load(Rsrc r, int off) {
   return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off(), off, 0));
 }
+__device__ __forceinline__ half8 buf_load_nt(Rsrc r, int off) {   // non-temporal: read once (another kernel's output stream)
+  return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off(), off, 2));
+}
 #endif

@@ -134,7 +134,11 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, char* smem, int l
       const char* src = !real ? srcB : (isA ? srcA + (size_t)p * 1024 : srcB + (size_t)(p - A_FRAGS) * 1024);
       const unsigned dst = !real ? dummy : (isA ? dst0 + p * 1024 : dst0 + KS * 1024 + (p - A_FRAGS) * 1024);
       const unsigned dst_u = __builtin_amdgcn_readfirstlane(dst);
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst_u) : "memory");
+      // the stashes are read exactly once by this kernel (d <= 256): non-temporal, so the stream does not displace the
+      // partial sums / weights other kernels left in L2 and lands sooner; at d = 512 two workgroups of an XCD read every
+      // byte and the second one should find it in L2
+      if (NQ == 1) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(src), "s"(dst_u) : "memory");
+      else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst_u) : "memory");
     }
   };
   // prologue: NBUF-1 chunks in flight (surplus issues re-read the first chunk: keeps the op count uniform)
