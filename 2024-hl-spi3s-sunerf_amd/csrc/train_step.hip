@@ -49,6 +49,30 @@ __device__ __forceinline__ bool last_block(unsigned* ticket) {
   return last != 0;
 }
 
+// Strided sweep of a float array with two 16-byte loads in flight per thread (a scalar grid-stride loop leaves every
+// thread with one 4-byte load per memory round trip: ~1 us each, 20 us per launch at training batch sizes).
+// `f` sees every element exactly once; the visiting order is fixed by (n, grid), so sums stay reproducible.
+typedef float ts_f4 __attribute__((ext_vector_type(4)));
+template <class F>
+__device__ __forceinline__ void sweep(const float* p, int64_t n, int64_t tid, int64_t stride, F f) {
+  if ((((uintptr_t)p) & 15) != 0) {
+    for (int64_t i = tid; i < n; i += stride) f(p[i]);
+    return;
+  }
+  const ts_f4* p4 = (const ts_f4*)p;
+  const int64_t n4 = n >> 2;
+  int64_t i = tid;
+  for (; i + stride < n4; i += 2 * stride) {
+    const ts_f4 u = p4[i], v = p4[i + stride];
+    f(u[0]); f(u[1]); f(u[2]); f(u[3]); f(v[0]); f(v[1]); f(v[2]); f(v[3]);
+  }
+  for (; i < n4; i += stride) {
+    const ts_f4 u = p4[i];
+    f(u[0]); f(u[1]); f(u[2]); f(u[3]);
+  }
+  for (int64_t j = (n4 << 2) + tid; j < n; j += stride) f(p[j]);
+}
+
 struct LossArgs {
   const float* coarse; const float* fine; const float* target;
   int64_t n;                   // elements of each image (N rays x W channels)
@@ -90,13 +114,12 @@ __global__ __launch_bounds__(TS_THREADS) void loss_kernel(LossArgs a) {
     a.g_coarse[i] = gscale * dc * scale_image_grad(a, c);
     a.g_fine[i] = gscale * df * scale_image_grad(a, f);
   }
-  for (int64_t i = tid; i < a.n_reg; i += stride) {
-    const float r = a.reg[i];
+  sweep(a.reg, a.n_reg, tid, stride, [&](float r) {
     bad += !isfinite(r);
     sum_r += r;
-  }
+  });
   for (int k = 0; k < a.n_extra; ++k)
-    for (int64_t i = tid; i < a.extra_n[k]; i += stride) bad += !isfinite(a.extra[k][i]);
+    sweep(a.extra[k], a.extra_n[k], tid, stride, [&](float x) { bad += !isfinite(x); });
 
   Workspace ws(a.workspace);
   const double b0 = block_sum((double)sq_c, sh), b1 = block_sum((double)sq_f, sh), b2 = block_sum((double)sum_r, sh),
@@ -139,10 +162,10 @@ __global__ __launch_bounds__(TS_THREADS) void grad_norm_kernel(NormArgs a) {
   __shared__ double sh[TS_THREADS / 64];
   const int64_t tid = (int64_t)blockIdx.x * TS_THREADS + threadIdx.x, stride = (int64_t)gridDim.x * TS_THREADS;
   float sq = 0.f;
-  for (int64_t i = tid; i < a.n; i += stride) {
-    const float g = a.grads[i] * a.grad_scale;
+  sweep(a.grads, a.n, tid, stride, [&](float x) {
+    const float g = x * a.grad_scale;
     sq += g * g;
-  }
+  });
   Workspace ws(a.workspace);
   const double b = block_sum((double)sq, sh);
   if (threadIdx.x == 0) ws.partial[(size_t)blockIdx.x * 4] = b;
