@@ -289,8 +289,10 @@ def main():
             dgrad = flops_bwd(D_FILTER) - flops_fwd(D_FILTER)
             executed_factor = (fwd_factor * flops_fwd(D_FILTER) + 2.0 * dgrad + flops_fwd(D_FILTER)) / flops_per_sample
         traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-        if os.path.exists(tpath):
+        for tname in ('hbm_traffic.json', 'hbm_traffic_d512.json'):
+            tpath = os.path.join(ROOT, 'profiles', tname)
+            if not os.path.exists(tpath):
+                continue
             with open(tpath) as f:
                 t = json.load(f)
             measured_on = t.get(f'{args.mode}_config', {})
