@@ -128,7 +128,7 @@ __device__ __forceinline__ void epi_stage_a(const f32x16& acc, int p, PairTmp& t
     asm volatile("" : "+v"(t.c0), "+v"(t.c1));
   }
 }
-template <bool STASH>
+template <bool STASH, bool HALF = false>
 __device__ __forceinline__ void epi_stage_b(PairTmp& t) {
   const f32x2 sv = {t.s0, t.s1};
   t.hi = __builtin_convertvector(sv, half2v);   // one v_cvt_pk_f16_f32 (round to nearest even)
@@ -136,8 +136,10 @@ __device__ __forceinline__ void epi_stage_b(PairTmp& t) {
   // remainder x - (float)hi in ONE instruction per element: v_fma_mix_f32 reads the fp16 half of the packed word directly
   // (fma(hi, -1, x): exact, bit-identical to convert-then-subtract -- tools/probes/probe_fma_mix.hip); saves the two
   // v_cvt_f32_f16 per pair in an epilogue that is bound by VALU issue slots
-  asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(t.r0) : "v"(t.hi), "v"(t.s0));
-  asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t.r1) : "v"(t.hi), "v"(t.s1));
+  if (!HALF) {   // (HALF: single fp16 operands, no remainders)
+    asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(t.r0) : "v"(t.hi), "v"(t.s0));
+    asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t.r1) : "v"(t.hi), "v"(t.s1));
+  }
   if (STASH) {
     const f32x2 cv = {t.c0, t.c1};
     t.cpk = __builtin_convertvector(cv, half2v);
@@ -148,13 +150,17 @@ __device__ __forceinline__ void epi_stage_b(PairTmp& t) {
 // from an H fragment to the matching cos fragment.  SPILL_OUT (d_filter = 512): the two activation sets do not fit the
 // register file together, so the finished hi / lo fragments go to this wave's global scratch at `sc`
 // ([fragment][hi 1 KiB | lo 1 KiB]) instead of staying in registers; they come back as the next layer's input.
-template <bool STASH, bool SPILL_OUT>
+template <bool STASH, bool SPILL_OUT, bool HALF = false>
 __device__ __forceinline__ void epi_stage_c(const PairTmp& t, int p, half8& hi0, half8& lo0, half8& hi1, half8& lo1,
                                             half8& ch0, half8& ch1, Rsrc st, int st_off, int cos_delta, Rsrc sc, int sc_off) {
-  half2v lo;
-  lo[0] = (_Float16)t.r0; lo[1] = (_Float16)t.r1;
-  if (p < 4) { hi0[2 * p] = t.hi[0]; hi0[2 * p + 1] = t.hi[1]; lo0[2 * p] = lo[0]; lo0[2 * p + 1] = lo[1]; }
-  else { hi1[2 * p - 8] = t.hi[0]; hi1[2 * p - 7] = t.hi[1]; lo1[2 * p - 8] = lo[0]; lo1[2 * p - 7] = lo[1]; }
+  if (p < 4) { hi0[2 * p] = t.hi[0]; hi0[2 * p + 1] = t.hi[1]; }
+  else { hi1[2 * p - 8] = t.hi[0]; hi1[2 * p - 7] = t.hi[1]; }
+  if (!HALF) {
+    half2v lo;
+    lo[0] = (_Float16)t.r0; lo[1] = (_Float16)t.r1;
+    if (p < 4) { lo0[2 * p] = lo[0]; lo0[2 * p + 1] = lo[1]; }
+    else { lo1[2 * p - 8] = lo[0]; lo1[2 * p - 7] = lo[1]; }
+  }
   if (STASH) {
     if (p < 4) { ch0[2 * p] = t.cpk[0]; ch0[2 * p + 1] = t.cpk[1]; }
     else { ch1[2 * p - 8] = t.cpk[0]; ch1[2 * p - 7] = t.cpk[1]; }
@@ -162,12 +168,12 @@ __device__ __forceinline__ void epi_stage_c(const PairTmp& t, int p, half8& hi0,
   // (pinning after every insertion instead makes hipcc rewrite the whole 4-dword tuple each time: measured worse)
   if (p == 3) {
     if (SPILL_OUT) { buf_store(hi0, sc, sc_off); buf_store(lo0, sc, sc_off + 1024); }
-    else { pin_agpr(hi0); pin_agpr(lo0); }
+    else { pin_agpr(hi0); if (!HALF) pin_agpr(lo0); }
     if (STASH) { buf_store_nt(hi0, st, st_off); buf_store_nt(ch0, st, st_off + cos_delta); }
   }
   if (p == 7) {
     if (SPILL_OUT) { buf_store(hi1, sc, sc_off + 2048); buf_store(lo1, sc, sc_off + 3072); }
-    else { pin_agpr(hi1); pin_agpr(lo1); }
+    else { pin_agpr(hi1); if (!HALF) pin_agpr(lo1); }
     if (STASH) { buf_store_nt(hi1, st, st_off + 1024); buf_store_nt(ch1, st, st_off + 1024 + cos_delta); }
   }
 }
@@ -196,7 +202,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 // the first k-steps of tile U.  One wave issues at most one instruction per ~4 cycles, so the per-k-step order is
 // pinned with sched_group_barrier: MFMA, a few VALU, a DS read, ... instead of leaving the epilogue as one clump
 // between two tiles.
-template <int D>
+// HALF (SUNERF_PRECISION_HALF): single fp16 operands -- only the head product of every k-step is issued, the lo fragments
+// of the weight stream and of the activations are never read or produced (the "bf16 weights on MFMA" class of BASELINE
+// config 3, with fp16's three extra mantissa bits); d <= 256 only.
+template <int D, bool HALF = false>
 struct Mlp {
   static constexpr int NT = D / 32;
   static constexpr int KS = D / 16;
@@ -238,7 +247,7 @@ struct Mlp {
   static __device__ __forceinline__ void load_frag(Pipe& p, int r, int ring_step) {
     const char* q = p.frag + ring_step * 2048;
     p.ahi[r] = *(const half8*)(q);
-    p.alo[r] = *(const half8*)(q + 1024);
+    if (!HALF) p.alo[r] = *(const half8*)(q + 1024);
   }
 
   // before the first k-step of the first chunk: pages 0 and 1 in flight, page 0 acquired, first PF k-steps requested
@@ -283,7 +292,7 @@ struct Mlp {
       const int r = (T0 + s) % PF;
       PairTmp t[PER];
       // --- MFMA 1 | stage A --------------------------------------------------------------------------------
-      acc = mfma16(p.alo[r], xhi[s], acc);
+      if (!HALF) acc = mfma16(p.alo[r], xhi[s], acc);
       if (HAS_PREV) {
 #pragma unroll
         for (int q = 0; q < PER; ++q)
@@ -291,11 +300,11 @@ struct Mlp {
       }
       __builtin_amdgcn_sched_barrier(0);
       // --- MFMA 2 | stage B --------------------------------------------------------------------------------
-      acc = mfma16(p.ahi[r], xlo[s], acc);
+      if (!HALF) acc = mfma16(p.ahi[r], xlo[s], acc);
       if (HAS_PREV) {
 #pragma unroll
         for (int q = 0; q < PER; ++q)
-          if (s * PER + q < 8) epi_stage_b<STASH>(t[q]);
+          if (s * PER + q < 8) epi_stage_b<STASH, HALF>(t[q]);
       }
       __builtin_amdgcn_sched_barrier(0);
       // --- MFMA 3 | stage C | next page | A-fragment reads of k-step s + PF --------------------------------------
@@ -303,7 +312,7 @@ struct Mlp {
       if (HAS_PREV) {
 #pragma unroll
         for (int q = 0; q < PER; ++q)
-          if (s * PER + q < 8) epi_stage_c<STASH, SPILL_OUT>(t[q], s * PER + q, yh0, yl0, yh1, yl1, ch0, ch1, st, st_off, cos_delta, sc, sc_out_off);
+          if (s * PER + q < 8) epi_stage_c<STASH, SPILL_OUT, HALF>(t[q], s * PER + q, yh0, yl0, yh1, yl1, ch0, ch1, st, st_off, cos_delta, sc, sc_out_off);
       }
       if (RELOAD) {   // fragments KIN-2, KIN-1 arrive through the carry epilogue of the next layer's first tile
         // requested at k-step s, moved into the operand registers RL k-steps later: committing right away would park the
@@ -840,9 +849,10 @@ struct Mlp8 : Mlp<D> {
   }
 };
 
-template <int D, bool STASH, bool FP8C>
+template <int D, bool STASH, bool FP8C, bool HALF = false>
 __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
-  using M = Mlp<D>;
+  static_assert(!HALF || (!FP8C && D <= 256), "HALF: classic stream format, both register sets resident");
+  using M = Mlp<D, HALF>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const PackedLayout L(D, a.n_linear);
   const StashLayout SL(D, a.n_linear);
@@ -1146,12 +1156,12 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two prefetches still in flight target our LDS: drain
 }
 
-template <int D, bool STASH, bool FP8C>
+template <int D, bool STASH, bool FP8C, bool HALF = false>
 int launch_render_t(const RenderArgs& a, hipStream_t stream) {
   const PackedLayout L(D, a.n_linear);
   const size_t lds = (size_t)Ring<D>::RING + L.n_bias() * 4;
   if (lds > 160 * 1024) return SUNERF_E_UNSUPPORTED;
-  hipError_t e = hipFuncSetAttribute((const void*)render_fwd_kernel<D, STASH, FP8C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute((const void*)render_fwd_kernel<D, STASH, FP8C, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   const int64_t n_groups = (a.n_rays + WAVES - 1) / WAVES;
   int dev = 0, cus = 256;
@@ -1160,7 +1170,7 @@ int launch_render_t(const RenderArgs& a, hipStream_t stream) {
   if (cus > 1024) cus = 1024;   // sunerf_render_workspace_bytes is sized for at most 1024 workgroups
   const unsigned grid = (unsigned)(n_groups < cus ? n_groups : cus);
   SUNERF_CLEAR_ERROR();
-  hipLaunchKernelGGL((render_fwd_kernel<D, STASH, FP8C>), dim3(grid), dim3(THREADS), lds, stream, a);
+  hipLaunchKernelGGL((render_fwd_kernel<D, STASH, FP8C, HALF>), dim3(grid), dim3(THREADS), lds, stream, a);
   SUNERF_CHECK_LAUNCH();
   return 0;
 }
@@ -1168,6 +1178,12 @@ template <int D>
 int launch_render(const RenderArgs& a, int precision, hipStream_t stream) {
   if (precision == SUNERF_PRECISION_FAST)
     return a.stash ? launch_render_t<D, true, true>(a, stream) : launch_render_t<D, false, true>(a, stream);
+  if (precision == SUNERF_PRECISION_HALF) {
+    if constexpr (D <= 256)
+      return a.stash ? launch_render_t<D, true, false, true>(a, stream) : launch_render_t<D, false, false, true>(a, stream);
+    else
+      return SUNERF_E_UNSUPPORTED;
+  }
   return a.stash ? launch_render_t<D, true, false>(a, stream) : launch_render_t<D, false, false>(a, stream);
 }
 
@@ -1193,7 +1209,8 @@ extern "C" int sunerf_emission_render_fwd(const void* packed, int d_filter, int 
                                           size_t workspace_bytes, void* stream) {
   if (n_rays < 0 || n_samples < 2) return SUNERF_E_BADARG;
   if (n_linear < 2 || n_linear > SUNERF_MAX_LAYERS) return SUNERF_E_UNSUPPORTED;
-  if (precision != SUNERF_PRECISION_FAST && precision != SUNERF_PRECISION_EXACT) return SUNERF_E_BADARG;
+  if (precision != SUNERF_PRECISION_FAST && precision != SUNERF_PRECISION_EXACT && precision != SUNERF_PRECISION_HALF)
+    return SUNERF_E_BADARG;
   if (n_rays == 0) return 0;      // an empty batch is valid (its tensors have null data pointers)
   if (!packed || !rays_o || !rays_d || !times || !z_vals || !image || !weights || !absorption) return SUNERF_E_BADARG;
   RenderArgs a;

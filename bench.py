@@ -173,8 +173,9 @@ def main():
     ap.add_argument('--d-filter', type=int, default=D_FILTER, help='MLP width (headline: 256; 512 = reference default)')
     args = ap.parse_args()
     globals()['D_FILTER'] = args.d_filter
-    fast = os.environ.get('SUNERF_FORWARD_PRECISION', 'fast').lower() != 'exact'
-    FP8C = 'true' if fast else 'false'
+    precision = os.environ.get('SUNERF_FORWARD_PRECISION', 'fast').lower()
+    fast, half = precision == 'fast', precision == 'half'
+    FP8C = ('true' if fast else 'false') + (', true' if half else '')
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -282,7 +283,7 @@ def main():
         achieved = rays_per_step * args.samples * flops_per_sample / (step_ms * 1e-3) / 1e12
         # matrix-pipe work of the forward per algorithmic flop: EXACT 3 fp16 products; FAST 1 fp16 product + two 64-deep
         # fp8 instructions per four 16-deep steps (measured 84 cycles each against 4 x 32: tools/probes/bench_mfma_mix.hip)
-        fwd_factor = 1.0 + 2.0 * 84.0 / 128.0 if fast else 3.0
+        fwd_factor = 1.0 if half else (1.0 + 2.0 * 84.0 / 128.0 if fast else 3.0)
         if args.mode == 'fwd':
             executed_factor = fwd_factor
         else:
@@ -304,7 +305,9 @@ def main():
             'metric': f'ray-samples/sec ({what}, fused emission renderer)', 'value': value, 'unit': 'ray-samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': ('f32 (forward: every operand split into an fp16 head and an exact remainder, head products on the fp16 '
+            'dtype': 'f16 MFMA operands, fp32 accumulate and parameters (opt-in HALF mode: the bf16-class arithmetic of BASELINE '
+                     'config 3; follows an fp16-emulating oracle to 1e-4, NOT the fp32 reference)' if half else
+                     ('f32 (forward: every operand split into an fp16 head and an exact remainder, head products on the fp16 '
                       'matrix cores + ' + ('block-scaled fp8 products for the two cross terms' if fast else 'fp16 products for the two cross terms')
                       + '; backward: fp16 MFMA, W^T hi + lo; fp32 accumulate and parameters)'),
             'data': 'synthetic',

@@ -140,6 +140,22 @@ def mlp_forward(params: Params, x: torch.Tensor, encoding: bool = True,
     return (out, hidden) if return_hidden else out
 
 
+def mlp_forward_half(params: Params, x: torch.Tensor) -> torch.Tensor:
+    """The MLP as the HALF arithmetic evaluates it (include/sunerf_hip.h, SUNERF_PRECISION_HALF): every operand of every
+    product rounded to fp16 -- the encoded input, the sine outputs, and the weights AFTER the 1/(2 pi) that the pack kernel
+    folds into the non-output layers (fp32 multiply, then round) -- products and sums exact (float64 here; fp32 on the
+    matrix cores), biases fp32, sin evaluated on the pre-activation in revolutions.  This is the emulated-low-precision
+    oracle of SURVEY.md section 8d ("bf16 configs: vs emulated oracle at 1e-4, deviation from fp32 reported")."""
+    inv2pi = torch.tensor(0.15915494309189535, dtype=torch.float32)
+    h = positional_encoding(x).to(torch.float16).to(torch.float64)
+    for W, b in params[:-1]:
+        w16 = (W.to(torch.float32) * inv2pi).to(torch.float16).to(torch.float64)
+        rev = h @ w16.T + (b.to(torch.float32) * inv2pi).to(torch.float64)
+        h = torch.sin(2 * math.pi * rev).to(torch.float32).to(torch.float16).to(torch.float64)
+    W, b = params[-1]
+    return (h @ W.to(torch.float16).to(torch.float64).T + b.to(torch.float64)).to(torch.float32)
+
+
 def init_params(d_filter: int = 256, n_layers: int = 8, d_in: int = 84, d_out: int = 2,
                 seed: int = 7) -> Params:
     """Default nn.Linear initialisation in the creation order of NeRF.__init__ (model.py:28-42):
@@ -192,13 +208,14 @@ def emission_integral(raw: torch.Tensor, z_vals: torch.Tensor, rays_d: torch.Ten
     return {'image': image, 'weights': weights, 'regularizing_quantity': absorption}
 
 
-def render_pass(params: Params, rays_o, rays_d, times, z_vals) -> Dict[str, torch.Tensor]:
+def render_pass(params: Params, rays_o, rays_d, times, z_vals, half: bool = False) -> Dict[str, torch.Tensor]:
     """One coarse or fine pass: time concat (base_tracing.py:64-65, :83-84), ``_render`` (:118-129, D1
-    resolved) and the emission integral."""
+    resolved) and the emission integral.  ``half``: the MLP in the emulated HALF arithmetic (``mlp_forward_half``)."""
     pts = points_on_rays(rays_o, rays_d, z_vals)
     exp_times = times[:, None].repeat(1, pts.shape[1], 1)
     query = torch.cat([pts, exp_times], -1)
-    raw = mlp_forward(params, query.view(-1, 4)).reshape(*query.shape[:-1], -1)
+    mlp = mlp_forward_half if half else mlp_forward
+    raw = mlp(params, query.view(-1, 4)).reshape(*query.shape[:-1], -1)
     out = emission_integral(raw, z_vals, rays_d)
     out['raw'] = raw
     out['points'] = pts
