@@ -136,7 +136,6 @@ extern "C" int sunerf_pack_mlp(const float* const* weights_host, const float* co
   }
   if (precision != SUNERF_PRECISION_FAST && precision != SUNERF_PRECISION_EXACT && precision != SUNERF_PRECISION_HALF)
     return SUNERF_E_BADARG;
-  if (precision == SUNERF_PRECISION_HALF && d_filter > 256) return SUNERF_E_UNSUPPORTED;
   a.n_linear = n_linear; a.D = d_filter; a.d_out = d_out; a.packed = (char*)packed;
   a.fp8c = precision == SUNERF_PRECISION_FAST;
   const PackedLayout L(d_filter, n_linear);

@@ -213,7 +213,8 @@ struct Mlp {
   static constexpr int PF = 4;                                   // prefetch distance in k-steps
   static constexpr int PAGE_STEPS = Ring<D>::PAGE_STEPS;         // k-steps per DMA page
   static constexpr int RING_STEPS = NSLOT * PAGE_STEPS;
-  static constexpr bool SPILL = D > 256;   // one activation set in registers, layer outputs via global scratch
+  // one activation set in registers, layer outputs via global scratch (HALF has no lo fragments: both sets fit at 512)
+  static constexpr bool SPILL = D > 256 && !HALF;
   static_assert(KS >= PF && SUNERF_KS0 >= PF, "prefetch distance exceeds a tile");
   static_assert((NT * SUNERF_KS0) % PF == 0 && KS % PF == 0, "fragment ring phase must be 0 at every layer start");
   static_assert((NT * SUNERF_KS0) % PAGE_STEPS == 0 && KS % PAGE_STEPS == 0, "layers must end on page boundaries");
@@ -391,6 +392,22 @@ struct Mlp {
         else
           acc = tile<KIN, T0, true, RS, STASH, true, LAST>(ring, p, acc, xhi, xlo, prev, th0, tl0, th1, tl1, st,
                                                            st_own + (2 * UU - 2) * 1024, CD, scratch, (2 * UU - 2) * 2048);
+        prev = acc;
+      });
+      return prev;
+    }
+    if constexpr (NT > 8) {   // (d = 512 in HALF mode: 16 tiles, both sets in registers; see the SPILL branch for static_for)
+      static_for<0, NT>([&](auto uu) {
+        constexpr int UU = decltype(uu)::value;
+        constexpr int RS = RSL0 < 0 ? -1 : (RSL0 + UU * KIN) % RING_STEPS;
+        constexpr int T0 = (UU * KIN) % PAGE_STEPS;
+        f32x16 acc = bias_tile(bias + 32 * UU, h);
+        if constexpr (UU == 0)
+          acc = tile<KIN, T0, HAS_CARRY, RS, STASH>(ring, p, acc, xhi, xlo, prev, xhi[XL], xlo[XL], xhi[XL + 1], xlo[XL + 1], st,
+                                                    st_prev + XL * 1024, CD, scratch);
+        else
+          acc = tile<KIN, T0, true, RS, STASH>(ring, p, acc, xhi, xlo, prev, yhi[2 * UU - 2], ylo[2 * UU - 2], yhi[2 * UU - 1],
+                                               ylo[2 * UU - 1], st, st_own + (2 * UU - 2) * 1024, CD, scratch);
         prev = acc;
       });
       return prev;
@@ -851,7 +868,7 @@ struct Mlp8 : Mlp<D> {
 
 template <int D, bool STASH, bool FP8C, bool HALF = false>
 __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
-  static_assert(!HALF || (!FP8C && D <= 256), "HALF: classic stream format, both register sets resident");
+  static_assert(!HALF || !FP8C, "HALF: classic stream format");
   using M = Mlp<D, HALF>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const PackedLayout L(D, a.n_linear);
@@ -1178,12 +1195,8 @@ template <int D>
 int launch_render(const RenderArgs& a, int precision, hipStream_t stream) {
   if (precision == SUNERF_PRECISION_FAST)
     return a.stash ? launch_render_t<D, true, true>(a, stream) : launch_render_t<D, false, true>(a, stream);
-  if (precision == SUNERF_PRECISION_HALF) {
-    if constexpr (D <= 256)
-      return a.stash ? launch_render_t<D, true, false, true>(a, stream) : launch_render_t<D, false, false, true>(a, stream);
-    else
-      return SUNERF_E_UNSUPPORTED;
-  }
+  if (precision == SUNERF_PRECISION_HALF)
+    return a.stash ? launch_render_t<D, true, false, true>(a, stream) : launch_render_t<D, false, false, true>(a, stream);
   return a.stash ? launch_render_t<D, true, false>(a, stream) : launch_render_t<D, false, false>(a, stream);
 }
 

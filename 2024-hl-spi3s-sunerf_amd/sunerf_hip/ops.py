@@ -20,14 +20,12 @@ PRECISION_FAST, PRECISION_EXACT, PRECISION_HALF = 0, 1, 2     # include/sunerf_h
 def default_precision(d_filter: int) -> int:
     """Forward arithmetic of newly packed models: ``SUNERF_FORWARD_PRECISION`` = ``fast`` (default: fp16 head product + two
     block-scaled fp8 correction products, fp32-class results), ``exact`` (three fp16 products per term) or ``half``
-    (opt-in, d_filter <= 256: single fp16 operands -- the bf16-class arithmetic of BASELINE config 3; NOT within 1e-4 of
+    (opt-in: single fp16 operands -- the bf16-class arithmetic of BASELINE config 3; NOT within 1e-4 of
     the fp32 reference)."""
     import os
     mode = os.environ.get('SUNERF_FORWARD_PRECISION', 'fast').lower()
     if mode not in ('fast', 'exact', 'half'):
         raise ValueError(f"SUNERF_FORWARD_PRECISION must be 'fast', 'exact' or 'half', not {mode!r}")
-    if mode == 'half' and d_filter > 256:
-        raise ValueError("SUNERF_FORWARD_PRECISION=half supports d_filter <= 256")
     return {'fast': PRECISION_FAST, 'exact': PRECISION_EXACT, 'half': PRECISION_HALF}[mode]
 
 

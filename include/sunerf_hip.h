@@ -42,7 +42,7 @@ extern "C" {
  *           (v_mfma_scale_f32_32x32x64_f8f6f4); raw MLP output within ~1e-5 |raw| rms (4e-5 |raw| worst sample) of fp32,
  *           i.e. images ~1e-5 rel for |raw| ~ 1: inside the 1e-4 parity gate; 18 % (d_filter 256) / 23 % (512) faster
  *   EXACT : all three terms as fp16 products (fp32-class results, raw within ~1e-7)
- *   HALF  : (d_filter <= 256, opt-in) single fp16 operands, fp32 accumulate: the head product only.  This is the
+ *   HALF  : (opt-in) single fp16 operands, fp32 accumulate: the head product only.  This is the
  *           "bf16 MLP weights on MFMA" class of BASELINE.json config 3 (with fp16's 11-bit instead of bf16's 8-bit
  *           mantissa): results follow an fp16-emulating evaluation to 1e-4 and deviate from fp32 by ~1e-3; it does NOT meet
  *           the 1e-4-vs-fp32 parity gate and is never the default */

@@ -131,7 +131,7 @@ def test_cpu_tensor_is_refused(ops):
         ops.sample_z(ops.SAMPLER_STRATIFIED, torch.zeros(4, 3), torch.ones(4, 3), torch.linspace(0, 1, 8), 1.3, 1.0)
 
 
-@pytest.mark.parametrize('d_filter,n_layers', [(256, 8), (128, 4), (64, 2)])
+@pytest.mark.parametrize('d_filter,n_layers', [(256, 8), (128, 4), (64, 2), (512, 3)])
 def test_half_precision_follows_emulated_oracle(ops, d_filter, n_layers, monkeypatch):
     """SUNERF_PRECISION_HALF (opt-in; BASELINE config 3's "bf16 weights on MFMA" class, here fp16 operands): parity with the
     oracle that rounds the same operands to fp16 (emulated oracle at 1e-4), and the deviation from the fp32
