@@ -167,6 +167,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32768, help='rays per rank and optimiser step (train mode)')
     ap.add_argument('--mode', choices=['train', 'fwd'], default='train')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-half', action='store_true', help='skip the HALF-precision figure reported beside the headline')
     ap.add_argument('--no-two-pass', action='store_true', help='skip the reference-shaped two-pass figure (train mode)')
     ap.add_argument('--dt', action='store_true', help='also time BASELINE config 5: density-temperature head, two-pass, '
                                                       '256 samples per ray in the fine pass (reported under "dt_two_pass")')
@@ -214,11 +215,11 @@ def main():
         n_rays = rays_o.shape[0]
         times = torch.zeros(n_rays, device=dev)
         z_vals = ops.sample_z(ops.SAMPLER_STRATIFIED, rays_o, rays_d, t_vals, 1.3, 1.0)
-        packed = model.packed()
         rays_per_step = n_rays
 
         def step(i):
-            return ops.emission_render_fwd(packed, rays_o, rays_d, times, z_vals, reg_radius=1.2, want_epilogues=True)['image']
+            return ops.emission_render_fwd(model.packed(), rays_o, rays_d, times, z_vals, reg_radius=1.2,
+                                           want_epilogues=True)['image']
         flops_per_sample, kernel_name = flops_fwd(D_FILTER), f'render_fwd_kernel<{D_FILTER}, false, {FP8C}>'
     else:
         # this rank's rows of the frame; batches of --batch rays cycle through them
@@ -268,6 +269,31 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
+    half_line = None
+    if precision == 'fast' and not args.no_half:
+        # beside the headline: the same step in the opt-in HALF arithmetic (single fp16 MFMA operands, fp32 accumulate --
+        # the "bf16 MLP weights on MFMA" class of BASELINE config 3).  Never the headline: it follows an fp16-emulating
+        # oracle to 1e-4, not the fp32 reference.
+        os.environ['SUNERF_FORWARD_PRECISION'] = 'half'
+        model._packed = None
+        hs = max(2, args.steps // 2)
+        for i in range(2):
+            step(i)
+        barrier()
+        th = time.perf_counter()
+        for i in range(hs):
+            step(2 + i)
+        barrier()
+        eh = torch.tensor([time.perf_counter() - th], device=dev)
+        if world > 1:
+            dist.all_reduce(eh, op=dist.ReduceOp.MAX)
+        os.environ['SUNERF_FORWARD_PRECISION'] = precision
+        model._packed = None
+        half_line = {'value': rays_per_step * args.samples * world * hs / eh.item(), 'unit': 'ray-samples/s',
+                     'ms_per_step': eh.item() / hs * 1e3, 'steps': hs,
+                     'what': 'the same step with SUNERF_FORWARD_PRECISION=half: single fp16 MFMA operands, fp32 accumulate '
+                             '(arithmetic class of BASELINE config 3); parity gate: fp16-emulating oracle at 1e-4, NOT the '
+                             'fp32 reference -- reported beside the headline, never as it'}
     two_pass = dt_two_pass = None
     if args.mode == 'train' and not args.no_two_pass:      # after the timed region of the headline metric
         del opt, model
@@ -327,6 +353,8 @@ def main():
                          # average HBM rate of the step against the 8 TB/s peak (PMC traffic of this configuration)
                          'hbm_frac': (traffic / (step_ms * 1e-3) / 8e12) if traffic else None},
         }
+        if half_line is not None:
+            line['half_precision'] = half_line
         if two_pass is not None:
             line['two_pass'] = two_pass
         if dt_two_pass is not None:

@@ -17,6 +17,6 @@ b bench_fwd_d512 --d-filter 512 --mode fwd
 SUNERF_FORWARD_PRECISION=exact b bench_train_d512_exact --d-filter 512 --no-two-pass --no-cpu-baseline
 SUNERF_FORWARD_PRECISION=exact b bench_fwd_d512_exact --d-filter 512 --mode fwd --no-cpu-baseline
 bash $R/tools/profile_round.sh
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/d512_stats -- python3 $R/bench.py --d-filter 512 --no-cpu-baseline --no-two-pass --steps 3 --warmup 1 --mode train > $O/d512_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/d512_stats -- python3 $R/bench.py --d-filter 512 --no-cpu-baseline --no-two-pass --no-half --steps 3 --warmup 1 --mode train > $O/d512_stats.log 2>&1
 bash $R/tools/profile_d512_traffic.sh > $O/d512_traffic.log 2>&1
 echo done
