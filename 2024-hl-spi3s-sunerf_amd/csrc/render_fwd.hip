@@ -1017,7 +1017,13 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
           }
         }
         v8i w8h = {0}, w8l = {0};                              // fp8 operands of the group under construction
+#if SUNERF_DBG_BARRIER
+        ring.dbg_kind = 0;
+#endif
         f32x16 carry = M8::template in_layer<STASH>(ring, pipe, bias, h, e_hi, e_lo, xa_hi, xa_h8, xa_l8, w8h, w8l, st, (int)SL.h_off(0));
+#if SUNERF_DBG_BARRIER
+        ring.dbg_kind = 1;
+#endif
         typename M8::Pipe8 q8;
         f32x16 pc = {0};                                       // correction accumulator of the pending tile (in layer: none)
         M8::preload(pipe, q8, M::RS_HIDDEN >= 0 ? M::RS_HIDDEN : pipe.rstep);
@@ -1034,8 +1040,14 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
                                                    xb_l8, xa_hi, xa_h8, xa_l8, w8h, w8l, carry, pc, st, (int)SL.h_off(l), (int)SL.h_off(l + 1));
         }
         if (l < a.n_linear - 1) {
+#if SUNERF_DBG_BARRIER
+          ring.dbg_kind = 2;
+#endif
           carry = M8::template hidden_layer<STASH>(ring, pipe, q8, bias + (size_t)l * D, h, scales(l), xa_hi, xa_h8, xa_l8, xb_hi,
                                                    xb_h8, xb_l8, w8h, w8l, carry, pc, st, (int)SL.h_off(l - 1), (int)SL.h_off(l));
+#if SUNERF_DBG_BARRIER
+          ring.dbg_kind = 3;
+#endif
           out = M8::template out_layer<STASH>(ring, pipe, q8, obias, h, scales(a.n_linear - 1), xb_hi, xb_h8, xb_l8, w8h, w8l, carry, pc, st,
                                               (int)SL.h_off(l));
         } else {
@@ -1171,6 +1183,12 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two prefetches still in flight target our LDS: drain
+#if SUNERF_DBG_BARRIER
+  if (lane == 0 && blockIdx.x < 64) {
+    float* o = a.weights + ((size_t)blockIdx.x * 4 + wave) * 16;
+    o[0] = (float)ring.dbg_vm; o[1] = (float)ring.dbg_bar; o[2] = (float)ring.dbg_n;
+  }
+#endif
 }
 
 template <int D, bool STASH, bool FP8C, bool HALF = false>

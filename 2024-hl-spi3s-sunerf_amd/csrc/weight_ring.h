@@ -3,6 +3,12 @@
 #pragma once
 #include "sunerf_common.h"
 
+#ifndef SUNERF_DBG_BARRIER
+#define SUNERF_DBG_BARRIER 0
+#endif
+#ifndef SUNERF_DBG_KIND
+#define SUNERF_DBG_KIND 1
+#endif
 namespace sunerf_ring {
 
 constexpr int WAVES = 4;
@@ -76,9 +82,22 @@ struct Ring {
   // the page being acquired, besides the PIECES of the following page
   template <int EXTRA = 0>
   __device__ __forceinline__ void acquire() {
+#if SUNERF_DBG_BARRIER
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PIECES + EXTRA) : "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+    if (dbg_kind == SUNERF_DBG_KIND) { dbg_vm += (unsigned)(t1 - t0); dbg_bar += (unsigned)(t2 - t1); dbg_n += 1; }
+#else
     asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PIECES + EXTRA) : "memory");
     __builtin_amdgcn_s_barrier();
+#endif
   }
+#if SUNERF_DBG_BARRIER
+  unsigned dbg_vm = 0, dbg_bar = 0, dbg_n = 0;
+  int dbg_kind = 0;
+#endif
 };
 
 }  // namespace sunerf_ring
