@@ -843,10 +843,12 @@ struct Mlp8 : Mlp<D> {
 #define SUNERF_TILE8(UU)                                                                                             \
       if (U == UU) {                                                                                                   \
         constexpr int RS = RS_HIDDEN < 0 ? -1 : (RS_HIDDEN + UU * KS) % RING_STEPS;                                    \
+        ring.mark_begin(UU == 0 ? 1 : (UU % 2 ? 2 : 3));   /* debug builds: 1 carry tile, 2 / 3 odd / even tile */      \
         if (UU == 0) acc = tile8<true, RS, STASH>(ring, p, q, acc, xhi, xh8, xl8, sc, prev, pc, XL, xhi, xh8, xl8, w8h, w8l, st, \
                                                   st_prev + XL * 1024, CD);                                           \
         else acc = tile8<true, RS, STASH>(ring, p, q, acc, xhi, xh8, xl8, sc, prev, pc, 2 * UU - 2, yhi, yh8, yl8, w8h, w8l, st, \
                                           st_own + (2 * UU - 2) * 1024, CD);                                          \
+        ring.mark_end(UU == 0 ? 1 : (UU % 2 ? 2 : 3));                                                                  \
       }
       SUNERF_TILE8(0) SUNERF_TILE8(1) SUNERF_TILE8(2) SUNERF_TILE8(3) SUNERF_TILE8(4) SUNERF_TILE8(5) SUNERF_TILE8(6) SUNERF_TILE8(7)
 #undef SUNERF_TILE8
@@ -889,6 +891,7 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
   typename M::Pipe pipe;
   pipe.frag = slot + lane * 16;
   M::start(ring, pipe);
+  ring.mark_begin(6);   // debug builds: 6 = the whole kernel after start-up
   const int S = a.S;
   const int n_chunks = (S + 31) >> 5;
   const int64_t n_groups = (a.n_rays + WAVES - 1) / WAVES;
@@ -1020,7 +1023,10 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
 #if SUNERF_DBG_BARRIER
         ring.dbg_kind = 0;
 #endif
+        ring.mark_end(5);
+        ring.mark_begin(0);
         f32x16 carry = M8::template in_layer<STASH>(ring, pipe, bias, h, e_hi, e_lo, xa_hi, xa_h8, xa_l8, w8h, w8l, st, (int)SL.h_off(0));
+        ring.mark_end(0);
 #if SUNERF_DBG_BARRIER
         ring.dbg_kind = 1;
 #endif
@@ -1048,8 +1054,11 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
 #if SUNERF_DBG_BARRIER
           ring.dbg_kind = 3;
 #endif
+          ring.mark_begin(4);
           out = M8::template out_layer<STASH>(ring, pipe, q8, obias, h, scales(a.n_linear - 1), xb_hi, xb_h8, xb_l8, w8h, w8l, carry, pc, st,
                                               (int)SL.h_off(l));
+          ring.mark_end(4);
+          ring.mark_begin(5);
         } else {
           out = M8::template out_layer<STASH>(ring, pipe, q8, obias, h, scales(a.n_linear - 1), xa_hi, xa_h8, xa_l8, w8h, w8l, carry, pc, st,
                                               (int)SL.h_off(l - 1));
@@ -1187,6 +1196,13 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
   if (lane == 0 && blockIdx.x < 64) {
     float* o = a.weights + ((size_t)blockIdx.x * 4 + wave) * 16;
     o[0] = (float)ring.dbg_vm; o[1] = (float)ring.dbg_bar; o[2] = (float)ring.dbg_n;
+  }
+#endif
+  ring.mark_end(6);
+#if SUNERF_DBG_TILES
+  if (lane == 0 && blockIdx.x < 64) {
+    float* o = a.weights + ((size_t)blockIdx.x * 4 + wave) * 16;
+    o[0] = (float)ring.dbg_cyc; o[1] = 0.f; o[2] = (float)ring.dbg_cnt;
   }
 #endif
 }

@@ -6,6 +6,12 @@
 #ifndef SUNERF_DBG_BARRIER
 #define SUNERF_DBG_BARRIER 0
 #endif
+#ifndef SUNERF_DBG_TILES
+#define SUNERF_DBG_TILES 0
+#endif
+#ifndef SUNERF_DBG_SHIFT
+#define SUNERF_DBG_SHIFT 0
+#endif
 #ifndef SUNERF_DBG_KIND
 #define SUNERF_DBG_KIND 1
 #endif
@@ -97,6 +103,19 @@ struct Ring {
 #if SUNERF_DBG_BARRIER
   unsigned dbg_vm = 0, dbg_bar = 0, dbg_n = 0;
   int dbg_kind = 0;
+#endif
+#if SUNERF_DBG_TILES
+  // cycles between mark_begin() and mark_end() of the regions tagged SUNERF_DBG_KIND (one kind per build: the counters
+  // live in SGPRs, of which the DMA addressing leaves few)
+  unsigned long long dbg_t0 = 0;
+  unsigned dbg_cyc = 0, dbg_cnt = 0;
+  __device__ __forceinline__ void mark_begin(int kind) { if (kind == SUNERF_DBG_KIND) dbg_t0 = __builtin_amdgcn_s_memtime(); }
+  __device__ __forceinline__ void mark_end(int kind) {
+    if (kind == SUNERF_DBG_KIND && dbg_t0 != 0) { dbg_cyc += (unsigned)((__builtin_amdgcn_s_memtime() - dbg_t0) >> SUNERF_DBG_SHIFT); dbg_cnt += 1; }
+  }
+#else
+  __device__ __forceinline__ void mark_begin(int) {}
+  __device__ __forceinline__ void mark_end(int) {}
 #endif
 };
 
