@@ -720,34 +720,36 @@ struct Mlp8 : Mlp<D> {
                                                    const f32x16& prev, int FP, half8* yhi, v8i* yh8, v8i* yl8, v8i& w8h,
                                                    v8i& w8l, Rsrc st, int st_off, int cos_delta, Rsrc scr = Rsrc()) {
     constexpr int KIN = SUNERF_KS0;
-    constexpr int EPI_STEPS = KIN - 2, PER = (8 + EPI_STEPS - 1) / EPI_STEPS;
     constexpr int ACQ = (PAGE_STEPS - PF) % PAGE_STEPS;
     half8 ch0, ch1;
     half8 th[2];
+    // The pending epilogue writes the y set, which nothing reads before the in layer is over: no deadline, so its 8
+    // micro-ops are spread over ALL k-steps (micro-op i behind k-step i KIN / 8: 2 1 1 2 1 1) -- with two per k-step on the
+    // first four, as the hidden tiles' deadline would demand, these short tiles were issue-bound at twice their matrix time
 #pragma unroll
     for (int s = 0; s < KIN; ++s) {
       const int r = (T0 + s) % PF;
-      PairTmp t[PER];
+      PairTmp t[2];
       acc = mfma16(p.alo[r], xhi[s], acc);
       if (HAS_PREV) {
 #pragma unroll
-        for (int e = 0; e < PER; ++e)
-          if (s * PER + e < 8) epi_stage_a<STASH>(prev, s * PER + e, t[e]);
+        for (int i = 0; i < 8; ++i)
+          if ((i * KIN) / 8 == s) epi_stage_a<STASH>(prev, i, t[i & 1]);
       }
       __builtin_amdgcn_sched_barrier(0);
       acc = mfma16(p.ahi[r], xlo[s], acc);
       if (HAS_PREV) {
 #pragma unroll
-        for (int e = 0; e < PER; ++e)
-          if (s * PER + e < 8) epi_stage_b<STASH>(t[e]);
+        for (int i = 0; i < 8; ++i)
+          if ((i * KIN) / 8 == s) epi_stage_b<STASH>(t[i & 1]);
       }
       __builtin_amdgcn_sched_barrier(0);
       acc = mfma16(p.ahi[r], xhi[s], acc);
       if (HAS_PREV) {
 #pragma unroll
-        for (int e = 0; e < PER; ++e)
-          if (s * PER + e < 8)
-            epi_stage_c8<STASH, SPILL_OUT>(t[e], s * PER + e, FP, yhi, yh8, yl8, w8h, w8l, ch0, ch1, st, st_off, cos_delta, scr, th);
+        for (int i = 0; i < 8; ++i)
+          if ((i * KIN) / 8 == s)
+            epi_stage_c8<STASH, SPILL_OUT>(t[i & 1], i, FP, yhi, yh8, yl8, w8h, w8l, ch0, ch1, st, st_off, cos_delta, scr, th);
       }
       {
         const int phase = (T0 + s) % PAGE_STEPS;
