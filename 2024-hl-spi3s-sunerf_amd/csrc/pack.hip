@@ -50,9 +50,13 @@ __device__ __forceinline__ int scale_exponent(unsigned absmax_bits) {
   if (!(m > 0.f)) return 0;
   int e;
   frexpf(m, &e);            // m = f 2^e, f in [0.5, 1)  =>  |w| < 2^e
-  return 8 - e;
+  // at most 21: a weight whose fp16 head is SUBNORMAL leaves a remainder of up to 2^-25 whatever the layer's scale, and
+  // 2^-25 2^(sh+11) must stay below the e4m3 maximum (a layer of max |w| < 2e-4 used to overflow to NaN here)
+  const int sh = 8 - e;
+  return sh > 21 ? 21 : sh;
 }
 __device__ __forceinline__ unsigned char to_fp8(float x) {   // OCP e4m3, round to nearest even, saturating
+  x = fminf(fmaxf(x, -448.f), 448.f);   // (the conversion itself turns an overflow into NaN)
   return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(x, 0.f, 0, false) & 0xff);
 }
 

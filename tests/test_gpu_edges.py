@@ -146,3 +146,20 @@ def test_reference_default_width_512_forward(ops, n_layers, S, precision):
     assert (out['raw'].cpu() - ref['raw']).abs().max().item() < 2e-5
     assert ((out['image'].cpu() - ref['image']).abs().max() / ref['image'].abs().max()).item() < 1e-4
     assert ((out['weights'].cpu() - ref['weights']).abs().max() / ref['weights'].abs().max()).item() < 1e-4
+
+
+@pytest.mark.parametrize('scale', [1e-3, 1e-6, 0.0])
+def test_tiny_weights_stay_finite(ops, scale, precision):
+    """Layers whose weights are all tiny (max |w| / 2 pi below the fp16 normal range): the fp8 scale search must not push the
+    remainders of subnormal fp16 heads past the e4m3 maximum (this used to give NaN images in the FAST arithmetic)."""
+    params = [(W * scale, b * scale) for W, b in orc.init_params(d_filter=64, n_layers=3, seed=2)]
+    o, d = orc.synthetic_rays(4)
+    t = torch.zeros(o.shape[0], 1)
+    z = orc.stratified_z(o, d, orc.linspace_t_vals(32), torch.tensor(1.3), torch.tensor(1.0))
+    ref = orc.render_pass(params, o, d, t, z)
+    packed = ops.PackedMLP([W.cuda() for W, _ in params], [b.cuda() for _, b in params])
+    out = ops.emission_render_fwd(packed, o.cuda(), d.cuda(), t.cuda(), z.cuda(), reg_radius=1.2, want_raw=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out['image']).all() and torch.isfinite(out['raw']).all()
+    assert (out['raw'].cpu() - ref['raw']).abs().max().item() < 1e-6 + 2e-5 * scale
+    assert ((out['image'].cpu() - ref['image']).abs().max() / ref['image'].abs().max()).item() < 1e-4
