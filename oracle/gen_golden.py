@@ -33,20 +33,53 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import ref_import  # noqa: E402
-import sunerf_oracle as orc  # noqa: E402  (only for the synthetic ray generator)
+import sunerf_oracle as orc  # noqa: E402  (only for the .genx table reader and the wavelength list)
 
-OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+GOLDEN = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+OUT = GOLDEN
 
 
 def npz(name, **arrays):
     arrays = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **arrays)
-    print(name, {k: v.shape for k, v in arrays.items()})
+    print(f'{name}: {len(arrays)} arrays')
 
 
-def test_rays(n_side, seed):
+# ---- frozen input generator ---------------------------------------------------------------------------------------
+# The fixture INPUTS are defined here and nowhere else, so that `python oracle/gen_golden.py` reproduces the committed
+# files bit for bit whatever happens to the oracle's own helpers (round 1: `orc.synthetic_rays` was changed after g1-g6
+# had been written and the script silently stopped regenerating them).  Two camera conventions are frozen:
+#   'plain'    rot_theta @ rot_phi @ trans (no axis permutation): the rays of g1, g3-g6 (any valid ray set pins a sampler /
+#              renderer; these happen to be the ones the committed outputs belong to)
+#   'observer' the reference's pose_spherical incl. the axis permutation (coordinate_transformation.py:36-54): g9, g10
+def _pose(theta, phi, radius, convention):
+    T = lambda rows: torch.Tensor(rows).float()   # noqa: E731
+    trans = T([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, radius], [0, 0, 0, 1]])
+    rphi = T([[1, 0, 0, 0], [0, np.cos(phi), -np.sin(phi), 0], [0, np.sin(phi), np.cos(phi), 0], [0, 0, 0, 1]])
+    rtheta = T([[np.cos(theta), 0, -np.sin(theta), 0], [0, 1, 0, 0], [np.sin(theta), 0, np.cos(theta), 0], [0, 0, 0, 1]])
+    if convention == 'plain':
+        return rtheta @ (rphi @ trans)
+    c2w = T([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    c2w = trans @ c2w
+    c2w = rphi @ c2w
+    c2w = rtheta @ c2w
+    return T([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]]) @ c2w
+
+
+def fixture_rays(resolution, convention, fov_half_rad=1.1 * 960. / 206264.806, theta=-0.3, phi=0.1, radius=215.032):
+    """(R*R, 3) origins and directions on a square helioprojective grid (the formula of data/ray_sampling.py:11-35)."""
+    c2w = _pose(theta, phi, radius, convention)
+    lin = torch.linspace(-fov_half_rad, fov_half_rad, resolution, dtype=torch.float64)
+    Ty, Tx = torch.meshgrid(lin, lin, indexing='ij')
+    directions = torch.stack([torch.sin(Tx), -torch.sin(Ty) * torch.cos(Tx), -torch.cos(Tx) * torch.cos(Ty)], -1).to(torch.float32)
+    rays_d = torch.sum(directions[..., None, :] * c2w[:3, :3], dim=-1).reshape(-1, 3)
+    rays_o = c2w[:3, -1].expand(rays_d.shape).contiguous()
+    return rays_o, rays_d.contiguous()
+
+
+def test_rays(n_side, seed, convention='plain'):
     """A mix of rays that hit the disk and rays that traverse the full slab, non-unit directions."""
-    o, d = orc.synthetic_rays(n_side)
+    o, d = fixture_rays(n_side, convention)
     g = torch.Generator().manual_seed(seed)
     d = d * (0.8 + 0.4 * torch.rand(d.shape[0], 1, generator=g))  # non-unit |d| exercises dists*|d|
     t = torch.rand(d.shape[0], 1, generator=g)
@@ -72,7 +105,7 @@ def main():
     out = st(o, d)
     sp = S.SphericalSampler(Rs_per_ds=1.0, distance=2.0, n_samples=32, perturb=False)
     # spherical needs rays that cross the 2 Rs sphere: tighter field of view
-    o2, d2 = orc.synthetic_rays(8, fov_half_rad=0.4 * 960. / 206264.806 * 2.0)
+    o2, d2 = fixture_rays(8, 'plain', fov_half_rad=0.4 * 960. / 206264.806 * 2.0)
     out_sp = sp(o2, d2)
     # perturb=True with a recorded t_rand: monkeypatch torch.rand for the call
     t_rand = torch.rand(64, 32, generator=torch.Generator().manual_seed(3))
@@ -307,7 +340,7 @@ def gen_g9(ref):
             for i, w in enumerate(orc.AIA_WAVELENGTHS):
                 m.log_absortpion[str(w)].fill_((1 + i) * 1e-9)
             m.volumetric_constant.fill_(0.7)
-    o, d = orc.synthetic_rays(6)                    # unit directions: monotonic z along the line of sight
+    o, d = fixture_rays(6, 'observer')              # unit directions: monotonic z along the line of sight
     t = torch.rand(o.shape[0], 1, generator=g)
     wl = torch.tensor([[94., 131., 171., 193., 211., 304., 335.]]).repeat(o.shape[0], 1)
     wl[2:5, 1] = 0.
@@ -341,7 +374,7 @@ def gen_g10(ref):
     torch.save(state, os.path.join(OUT, 'g10_reference_state.snf'))
     shim = ref_import.shimmed_emission_class()(**{k: (dict(v) if isinstance(v, dict) else v) for k, v in cfg.items()})
     shim.load_state_dict(plain.state_dict())
-    o, d, t = test_rays(5, seed=6)
+    o, d, t = test_rays(5, seed=6, convention='observer')
     with torch.no_grad():
         outputs = shim(o, d, t)
         pts = torch.rand(33, 4, generator=torch.Generator().manual_seed(1)) * 2 - 1
@@ -351,12 +384,61 @@ def gen_g10(ref):
     npz('g10_reference_state', **arrays)
 
 
+def compare_with_committed(out_dir):
+    """Bit-compares every array of every fixture in ``out_dir`` with the committed file of the same name.
+    Returns a list of human-readable differences (empty = the script reproduces the committed fixtures)."""
+    diffs = []
+    for name in sorted(os.listdir(GOLDEN)):
+        if not name.endswith('.npz'):
+            continue
+        new_path = os.path.join(out_dir, name)
+        if not os.path.exists(new_path):
+            diffs.append(f'{name}: not regenerated')
+            continue
+        a, b = np.load(os.path.join(GOLDEN, name), allow_pickle=False), np.load(new_path, allow_pickle=False)
+        if sorted(a.files) != sorted(b.files):
+            diffs.append(f'{name}: key sets differ: {sorted(set(a.files) ^ set(b.files))}')
+            continue
+        for k in a.files:
+            x, y = a[k], b[k]
+            if x.shape != y.shape or x.dtype != y.dtype or x.tobytes() != y.tobytes():
+                diffs.append(f'{name}[{k}] differs')
+    return diffs
+
+
+def generate(out_dir=None, only=None):
+    """Regenerates the fixtures into ``out_dir`` (default: tests/golden)."""
+    global OUT
+    OUT = GOLDEN if out_dir is None else out_dir
+    try:
+        if only:
+            torch.manual_seed(7)
+            torch.set_num_threads(1)
+            ref = ref_import.import_reference()
+            for a in only:
+                {'g7': gen_g7, 'g8': gen_g8, 'g9': gen_g9, 'g10': gen_g10}[a](ref)
+            ref_import.release_reference()
+        else:
+            main()
+    finally:
+        OUT = GOLDEN
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and all(a in ('g7', 'g8', 'g9', 'g10') for a in sys.argv[1:]):
-        torch.manual_seed(7)
-        torch.set_num_threads(1)
-        ref = ref_import.import_reference()
-        for a in sys.argv[1:]:
-            {'g7': gen_g7, 'g8': gen_g8, 'g9': gen_g9, 'g10': gen_g10}[a](ref)
-    else:
-        main()
+    import argparse
+    ap = argparse.ArgumentParser(description=__doc__.split('\n')[0])
+    ap.add_argument('--out', default=None, help='write the fixtures here instead of tests/golden')
+    ap.add_argument('--check', action='store_true',
+                    help='regenerate into a scratch directory and bit-compare with the committed fixtures')
+    ap.add_argument('only', nargs='*', help='regenerate only these (g7 g8 g9 g10)')
+    args = ap.parse_args()
+    if any(a not in ('g7', 'g8', 'g9', 'g10') for a in args.only):
+        ap.error('only g7 g8 g9 g10 can be regenerated on their own')
+    if args.check:
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            generate(tmp)
+            diffs = compare_with_committed(tmp)
+        print('\n'.join(diffs) if diffs else 'all committed fixtures reproduce bit for bit')
+        sys.exit(1 if diffs else 0)
+    generate(args.out, args.only)
