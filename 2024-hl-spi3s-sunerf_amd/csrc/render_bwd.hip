@@ -11,7 +11,8 @@
 // Numerics: dZ and the activations enter the matrix products as single fp16 operands, W^T as hi + lo (fp32 accumulate): the reference tolerance for gradients
 // is 1e-3 relative per tensor and the rounding errors (2^-12 relative, unbiased) average out over the samples.  fp16 has
 // a narrow exponent range, so g_raw is multiplied by a power of two `gscale` chosen from max|g_raw| of the batch
-// (computed on the device, no host round trip) and dW / db are multiplied by 1/gscale at the end.
+// (computed on the device, no host round trip) and dW / db are multiplied by 1/gscale at the end (sunerf_common.h:
+// SUNERF_GSCALE_LOG2); the hidden data gradients saturate at +-65504 instead of overflowing.
 #include "sunerf_common.h"
 #include "weight_ring.h"
 #include "../../include/sunerf_hip.h"
@@ -137,14 +138,7 @@ struct DgradArgs {
   int n_linear;
 };
 
-__device__ __forceinline__ float gscale_from_bits(unsigned bits) {
-  // power of two that brings max|g_raw| to ~2^10 (fp16 max 65504; partial sums over <= 2 outputs stay far below)
-  const float m = __uint_as_float(bits);
-  if (!(m > 0.f)) return 1.f;
-  int e;
-  frexpf(m, &e);                 // m = f * 2^e, f in [0.5, 1)
-  return ldexpf(1.f, 10 - e);
-}
+__device__ __forceinline__ float gscale_from_bits(unsigned bits) { return sunerf_gscale(bits); }
 
 __device__ __forceinline__ void pin_agpr(half8& f) { asm volatile("" : "+a"(f)); }
 
@@ -152,8 +146,8 @@ __device__ __forceinline__ void pin_agpr(half8& f) { asm volatile("" : "+a"(f));
 __device__ __forceinline__ void dz_tile(const f32x16& acc, const half8& c0, const half8& c1, half8& d0, half8& d1) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    d0[j] = (_Float16)(acc[j] * (float)c0[j]);
-    d1[j] = (_Float16)(acc[8 + j] * (float)c1[j]);
+    d0[j] = (_Float16)sunerf_sat16(acc[j] * (float)c0[j]);
+    d1[j] = (_Float16)sunerf_sat16(acc[8 + j] * (float)c1[j]);
   }
 }
 
@@ -272,8 +266,8 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_pair_kernel(DgradArgs a) 
         const int q = k & 1, pp = k >> 1;                     // constants after unrolling
         const f32x16& acc = q ? prev1 : prev0;
         const half8& c = (q ? cw1 : cw0)[2 * ws + (pp >> 2)];
-        float v0 = acc[2 * pp] * (float)c[(2 * pp) & 7];
-        float v1 = acc[2 * pp + 1] * (float)c[(2 * pp + 1) & 7];
+        float v0 = sunerf_sat16(acc[2 * pp] * (float)c[(2 * pp) & 7]);
+        float v1 = sunerf_sat16(acc[2 * pp + 1] * (float)c[(2 * pp + 1) & 7]);
         const f32x2 vv = {v0, v1};
         half2v pk = __builtin_convertvector(vv, half2v);
         asm volatile("" : "+v"(pk));                           // anchor: keep the micro-op in its k-step

@@ -121,6 +121,28 @@ __host__ __device__ inline int acc_row(int g, int h) { return (g & 3) + 8 * (g >
     if (e__ != hipSuccess) return (int)e__;           \
   } while (0)
 
+// Backward pass: the loss gradient w.r.t. the raw MLP output is multiplied by a power of two chosen from max|g_raw| of the
+// batch (found on the device) before it enters the fp16 matrix products, and dW / db are multiplied by its inverse at the
+// end.  max|g_raw| is placed at 2^SUNERF_GSCALE_LOG2 = 16: the data gradients of the hidden layers then have 2^12 of
+// head-room before fp16 saturates at 65504 -- a network whose layers amplify gradients (trained / large weights: gain g
+// per layer grows dZ by g^7 over an 8-layer net; all hidden weights x 4 is 2^8.4) stays finite, where the former
+// placement at 2^10 left 2^6.  Downwards nothing is lost that matters: gfx950's MFMA honours fp16 subnormals, so a value
+// 2^-18 of the maximum still carries an absolute error of only 2^-29 of the maximum.
+#define SUNERF_GSCALE_LOG2 4
+#if defined(__HIPCC__)
+__device__ __forceinline__ int sunerf_gscale_exponent(unsigned absmax_bits) {   // e with max|g_raw| = f 2^e, f in [0.5, 1)
+  const float m = __uint_as_float(absmax_bits);
+  int e = SUNERF_GSCALE_LOG2;
+  if (m > 0.f) frexpf(m, &e);
+  return e;
+}
+__device__ __forceinline__ float sunerf_gscale(unsigned absmax_bits) { return ldexpf(1.f, SUNERF_GSCALE_LOG2 - sunerf_gscale_exponent(absmax_bits)); }
+__device__ __forceinline__ float sunerf_gscale_inv(unsigned absmax_bits) { return ldexpf(1.f, sunerf_gscale_exponent(absmax_bits) - SUNERF_GSCALE_LOG2); }
+// fp32 -> fp16 pair that SATURATES at +-65504 instead of overflowing to infinity (a few saturated elements bend a gradient
+// that the clip will rescale anyway; an infinity becomes NaN in the weight gradients and costs the whole step)
+__device__ __forceinline__ float sunerf_sat16(float v) { return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
+#endif
+
 #if defined(__HIPCC__)
 // Stash and scratch traffic goes through BUFFER instructions: wave-uniform base in a scalar resource descriptor, the lane
 // part (lane * 16) as the one VGPR offset, the many constant fragment offsets as scalar offsets / immediates.  With per-lane

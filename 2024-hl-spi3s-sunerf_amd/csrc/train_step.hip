@@ -154,8 +154,11 @@ __global__ __launch_bounds__(TS_THREADS) void loss_kernel(LossArgs a) {
 struct NormArgs {
   const float* grads; int64_t n;
   float grad_scale, max_norm;
-  float* norm_out;      // [total norm (after grad_scale), clip coefficient]
-  void* workspace;
+  const float* skip_if;     // optional device scalar: a value > 0 (non-finite outputs seen on ANY rank) skips the update
+  long long* step_dev;      // optional device counter of APPLIED updates (a skipped step does not advance the bias correction)
+  long long step_host;      // step number to use when there is no device counter
+  float* norm_out;          // [total norm (after grad_scale), clip coefficient, skipped (0 / 1), 0]
+  void* workspace;          // bytes 8..15: step number of this update (read by adam_kernel)
 };
 
 __global__ __launch_bounds__(TS_THREADS) void grad_norm_kernel(NormArgs a) {
@@ -178,8 +181,20 @@ __global__ __launch_bounds__(TS_THREADS) void grad_norm_kernel(NormArgs a) {
     // clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1; max_norm <= 0 disables clipping
     float coef = 1.f;
     if (a.max_norm > 0.f) coef = fminf(a.max_norm / (total + 1e-6f), 1.f);
+    // The update is skipped -- on every rank alike, because both inputs are results of the all-reduce -- when a non-finite
+    // output was counted anywhere (sunerf.py:105-107 would have asserted) or when the gradient itself is not finite (a NaN
+    // norm would otherwise become a NaN clip coefficient and reach every parameter).
+    const bool skip = (a.skip_if && !(*a.skip_if <= 0.f)) || !isfinite(total);
+    long long step = a.step_host;
+    if (a.step_dev) {
+      step = *a.step_dev + 1;
+      if (!skip) *a.step_dev = step;
+    }
     a.norm_out[0] = total;
     a.norm_out[1] = coef;
+    a.norm_out[2] = skip ? 1.f : 0.f;
+    a.norm_out[3] = 0.f;
+    *(long long*)((char*)a.workspace + 8) = step;
     *ws.ticket = 0;
   }
 }
@@ -187,24 +202,36 @@ __global__ __launch_bounds__(TS_THREADS) void grad_norm_kernel(NormArgs a) {
 struct AdamArgs {
   float* params; float* grads; float* exp_avg; float* exp_avg_sq; int64_t n;
   float grad_scale;
-  const float* norm;          // [total, clip coefficient] from grad_norm_kernel, or null (no clipping)
-  const float* skip_if;       // optional device scalar: a value > 0 (non-finite outputs seen) leaves everything untouched
-  float one_minus_beta1, beta2, one_minus_beta2, eps;
-  float step_size;            // lr / (1 - beta1^t)
-  float bias_correction2_sqrt;
+  const float* norm;          // [total, clip coefficient, skipped] from grad_norm_kernel, or null (legacy: no norm pass)
+  const float* skip_if;       // legacy path only (norm == null): a value > 0 leaves everything untouched
+  const void* workspace;      // bytes 8..15: step number (norm != null)
+  long long step_host;
+  double lr, beta1, beta2;
+  float one_minus_beta1, beta2f, one_minus_beta2, eps;
 };
 
 __global__ __launch_bounds__(TS_THREADS) void adam_kernel(AdamArgs a) {
-  if (a.skip_if && *a.skip_if > 0.f) return;
-  const float coef = a.norm ? a.norm[1] : 1.f;
+  long long step = a.step_host;
+  float coef = 1.f;
+  if (a.norm) {
+    if (a.norm[2] > 0.f) return;
+    coef = a.norm[1];
+    step = *(const long long*)((const char*)a.workspace + 8);
+  } else if (a.skip_if && !(*a.skip_if <= 0.f)) {
+    return;
+  }
+  // scalars exactly as torch/optim/adam.py forms them (python floats = doubles, rounded to fp32 when they meet a tensor)
+  const double bc1 = 1.0 - pow(a.beta1, (double)step), bc2 = 1.0 - pow(a.beta2, (double)step);
+  const float step_size = (float)(a.lr / bc1);
+  const float bias_correction2_sqrt = (float)sqrt(bc2);
   const int64_t tid = (int64_t)blockIdx.x * TS_THREADS + threadIdx.x, stride = (int64_t)gridDim.x * TS_THREADS;
   for (int64_t i = tid; i < a.n; i += stride) {
     const float g = (a.grads[i] * a.grad_scale) * coef;
     float m = a.exp_avg[i], v = a.exp_avg_sq[i];
     m = m + a.one_minus_beta1 * (g - m);                      // exp_avg.lerp_(grad, 1 - beta1)
-    v = v * a.beta2 + (a.one_minus_beta2 * g) * g;             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-    const float denom = sqrtf(v) / a.bias_correction2_sqrt + a.eps;
-    a.params[i] = a.params[i] + (-a.step_size * m) / denom;   // param.addcdiv_(exp_avg, denom, value=-step_size)
+    v = v * a.beta2f + (a.one_minus_beta2 * g) * g;            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    const float denom = sqrtf(v) / bias_correction2_sqrt + a.eps;
+    a.params[i] = a.params[i] + (-step_size * m) / denom;     // param.addcdiv_(exp_avg, denom, value=-step_size)
     a.exp_avg[i] = m;
     a.exp_avg_sq[i] = v;
     a.grads[i] = g;                                           // the clipped, averaged gradient (what the reference leaves in .grad)
@@ -255,33 +282,34 @@ extern "C" int sunerf_training_loss(const float* coarse_image, const float* fine
 extern "C" int sunerf_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
                                      double beta1, double beta2, double eps, float max_norm, float grad_scale, int64_t step,
                                      const float* skip_if_positive, float* norm_out, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
-  if (n < 0 || step < 1) return SUNERF_E_BADARG;
+                                     size_t workspace_bytes, void* step_counter, void* stream) {
+  if (n < 0 || (step < 1 && !step_counter)) return SUNERF_E_BADARG;
   if (n == 0) return 0;
   if (!params || !grads || !exp_avg || !exp_avg_sq) return SUNERF_E_BADARG;
-  if (max_norm > 0.f && (!norm_out || !workspace)) return SUNERF_E_BADARG;
-  if (max_norm > 0.f && workspace_bytes < sunerf_train_workspace_bytes()) return SUNERF_E_WORKSPACE;
+  const bool norm_pass = norm_out && workspace;
+  if ((max_norm > 0.f || step_counter) && !norm_pass) return SUNERF_E_BADARG;
+  if (norm_pass && workspace_bytes < sunerf_train_workspace_bytes()) return SUNERF_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   SUNERF_CLEAR_ERROR();
-  if (max_norm > 0.f) {
+  if (norm_pass) {
     NormArgs na;
     na.grads = grads; na.n = n; na.grad_scale = grad_scale; na.max_norm = max_norm; na.norm_out = norm_out;
+    na.skip_if = skip_if_positive; na.step_dev = (long long*)step_counter; na.step_host = step;
     na.workspace = workspace;
     hipLaunchKernelGGL(grad_norm_kernel, dim3(blocks_for(n)), dim3(TS_THREADS), 0, st, na);
     SUNERF_CHECK_LAUNCH();
   }
   AdamArgs a;
   a.params = params; a.grads = grads; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.n = n; a.grad_scale = grad_scale;
-  a.norm = max_norm > 0.f ? norm_out : nullptr;
+  a.norm = norm_pass ? norm_out : nullptr;
   a.skip_if = skip_if_positive;
-  // scalars exactly as torch/optim/adam.py forms them (python floats = doubles, rounded to fp32 when they meet a tensor)
-  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  a.workspace = workspace;
+  a.step_host = step;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2;
   a.one_minus_beta1 = (float)(1.0 - beta1);
-  a.beta2 = (float)beta2;
+  a.beta2f = (float)beta2;
   a.one_minus_beta2 = (float)(1.0 - beta2);
   a.eps = (float)eps;
-  a.step_size = (float)(lr / bc1);
-  a.bias_correction2_sqrt = (float)sqrt(bc2);
   // no reduction here: as many workgroups as the elements need (the reductions above are capped at TS_BLOCKS partials)
   const int64_t adam_blocks = (n + TS_THREADS - 1) / TS_THREADS;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(adam_blocks > 4096 ? 4096 : adam_blocks)), dim3(TS_THREADS), 0, st, a);

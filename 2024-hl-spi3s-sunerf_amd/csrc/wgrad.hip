@@ -34,13 +34,7 @@ struct WgradArgs {
   int lds_bytes;
 };
 
-__device__ __forceinline__ float gscale_from_bits(unsigned bits) {
-  const float m = __uint_as_float(bits);
-  if (!(m > 0.f)) return 1.f;
-  int e;
-  frexpf(m, &e);
-  return ldexpf(1.f, 10 - e);
-}
+__device__ __forceinline__ float gscale_from_bits(unsigned bits) { return sunerf_gscale(bits); }
 
 // transposed read of one MFMA operand (32 features x 16 samples) from a fragment pair staged in LDS: two
 // ds_read_b64_tr_b16 (4 samples each); issue-only -- the caller waits once for a whole batch of operands.
@@ -301,9 +295,7 @@ __global__ void reduce_grads_kernel(ReduceArgs a) {
   const float* p = a.partial + (size_t)layer * a.split * slot + ((size_t)tr * (T + 1) + tc) * 1024 + reg * 64 + lane;
   float sum = 0.f;
   for (int s = 0; s < a.split; ++s) sum += p[(size_t)s * slot];
-  const float m = __uint_as_float(*a.g_absmax_bits);
-  float inv = 1.f;
-  if (m > 0.f) { int e; frexpf(m, &e); inv = ldexpf(1.f, e - 10); }
+  const float inv = sunerf_gscale_inv(*a.g_absmax_bits);
   float* dst = (tc == T) ? a.gb[layer] + j : a.gW[layer] + (size_t)j * cols + k;
   *dst = a.accumulate ? *dst + sum * inv : sum * inv;
 }

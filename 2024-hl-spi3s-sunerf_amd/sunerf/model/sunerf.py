@@ -58,16 +58,20 @@ class BaseSuNeRFModule(LightningModule):
 
     def _finish_step(self, loss, stats):
         self.last_stats = stats
-        if self.strict_finite_check:
+        # under data parallelism the assert must be taken by every rank together (a rank that raised alone would leave the
+        # others waiting in the all-reduce): there it is made after the optimiser step, on the all-reduced count
+        if self.strict_finite_check and not _data_parallel():
             self.check_finite()
         self.log('loss', loss)
         self.log('train', {'coarse': stats[1], 'fine': stats[2], 'regularization': stats[3], 'psnr': stats[4]})
         return loss
 
-    def check_finite(self):
-        stats = getattr(self, 'last_stats', None)
-        if stats is not None:
-            assert stats[5].item() == 0, '! [Numerical Alert] an output contains NaN or Inf.'
+    def check_finite(self, optimizer=None):
+        """The reference's NaN / Inf assert (sunerf.py:105-107) as one 4-byte read: of this rank's counter, or -- given
+        the optimiser after its step -- of the count summed over all ranks."""
+        count = optimizer.nonfinite if optimizer is not None else getattr(self, 'last_stats', [None] * 6)[5]
+        if count is not None:
+            assert float(count) == 0, '! [Numerical Alert] an output contains NaN or Inf.'
 
     def on_train_batch_end(self, *args, **kwargs):
         if self.scheduler.get_last_lr()[0] > 5e-5:
@@ -75,22 +79,28 @@ class BaseSuNeRFModule(LightningModule):
         self.log('Learning Rate', self.scheduler.get_last_lr()[0])
 
     def validation_epoch_end(self, outputs_list):
-        if len(outputs_list) == 0:
+        """sunerf.py:42-54: concatenates the per-batch dicts of every validation set and files them under the set's name.
+        Accepts a list of batch dicts (one validation set) or a list of such lists; nothing is stored when any set is empty."""
+        per_set = outputs_list
+        if per_set and isinstance(per_set[0], dict):
+            per_set = [per_set]
+        if not per_set or not all(len(batches) for batches in per_set):
+            if per_set:
+                self.validation_outputs = {}
             return
-        self.validation_outputs = {}
-        if isinstance(outputs_list[0], dict):
-            outputs_list = [outputs_list]
-        if len(outputs_list) == 0 or any([len(o) == 0 for o in outputs_list]):
-            return
-        for i, outputs in enumerate(outputs_list):
-            out_keys = outputs[0].keys()
-            outputs = {k: torch.cat([o[k] for o in outputs]) for k in out_keys}
-            self.validation_outputs[self.validation_dataset_mapping[i]] = outputs
+        self.validation_outputs = {
+            self.validation_dataset_mapping[i]: {key: torch.cat([b[key] for b in batches]) for key in batches[0]}
+            for i, batches in enumerate(per_set)}
 
     def on_load_checkpoint(self, checkpoint):
-        state_dict = checkpoint['state_dict']
-        self.load_state_dict(state_dict, strict=False)
+        """sunerf.py:56-59: non-strict restore (checkpoints written before a module gained a buffer still load)."""
         self.validation_outputs = {}
+        self.load_state_dict(checkpoint['state_dict'], strict=False)
+
+
+def _data_parallel() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
 def _other_outputs(outputs):
@@ -225,6 +235,8 @@ def fit_steps(module: BaseSuNeRFModule, batches, gradient_clip_val=0.5):
         loss.backward()
         stats = getattr(module, 'last_stats', None)
         optimizer.step(skip_if_positive=None if stats is None else stats[5:6])
+        if module.strict_finite_check and _data_parallel():
+            module.check_finite(optimizer)
         module.on_train_batch_end()
         losses.append(loss.detach())
     return losses

@@ -12,35 +12,31 @@ from sunerf.model.model import NeRF
 from sunerf.train.sampling import SphericalSampler, HierarchicalSampler, StratifiedSampler
 
 
+_SAMPLERS = {'spherical': SphericalSampler, 'stratified': StratifiedSampler}
+_RESAMPLERS = {'hierarchical': HierarchicalSampler}
+
+
+def _from_config(registry, config, default_type, **fixed):
+    """Builds ``registry[config['type']](**fixed, **rest of config)``.  Like the reference (base_tracing.py:24, :33) the
+    ``'type'`` key is POPPED from the caller's dict, and an unknown type is a ``ValueError`` with the reference's text."""
+    config = {'type': default_type} if config is None else config
+    kind = config.pop('type')
+    if kind not in registry:
+        raise ValueError(f'Unknown sampling type {kind}')
+    return registry[kind](**fixed, **config)
+
+
 class SuNeRFRendering(nn.Module):
+    """base_tracing.py:8-132: owns the two samplers and the coarse / fine field models; subclasses supply ``forward``."""
 
     def __init__(self, Rs_per_ds, sampling_config=None, hierarchical_sampling_config=None, model=NeRF,
                  model_config=None):
         super().__init__()
         self.Rs_per_ds = Rs_per_ds
-
-        hierarchical_sampling_config = {'type': 'hierarchical'} \
-            if hierarchical_sampling_config is None else hierarchical_sampling_config
-        sampling_config = {'type': 'stratified'} if sampling_config is None else sampling_config
-        model_config = {} if model_config is None else model_config
-
-        # NOTE: like the reference (base_tracing.py:24,33) the 'type' key is popped from the caller's dict
-        sampling_type = sampling_config.pop('type')
-        if sampling_type == 'spherical':
-            self.sampler = SphericalSampler(Rs_per_ds=Rs_per_ds, **sampling_config)
-        elif sampling_type == 'stratified':
-            self.sampler = StratifiedSampler(Rs_per_ds=Rs_per_ds, **sampling_config)
-        else:
-            raise ValueError(f'Unknown sampling type {sampling_type}')
-
-        hierarchical_sampling_type = hierarchical_sampling_config.pop('type')
-        if hierarchical_sampling_type == 'hierarchical':
-            self.sampler_hierarchical = HierarchicalSampler(**hierarchical_sampling_config)
-        else:
-            raise ValueError(f'Unknown sampling type {hierarchical_sampling_type}')
-
-        self.coarse_model = model(**model_config)
-        self.fine_model = model(**model_config)
+        self.sampler = _from_config(_SAMPLERS, sampling_config, 'stratified', Rs_per_ds=Rs_per_ds)
+        self.sampler_hierarchical = _from_config(_RESAMPLERS, hierarchical_sampling_config, 'hierarchical')
+        model_config = model_config or {}
+        self.coarse_model, self.fine_model = model(**model_config), model(**model_config)
 
     def regularization(self, distance, regularizing_quantity):
         # base_tracing.py:43-44 with D2 resolved: (N, S)
@@ -51,16 +47,15 @@ class SuNeRFRendering(nn.Module):
 
     def forward_points(self, query_points):
         # base_tracing.py:113-116 with D3 resolved: the tensor, not the dict
-        flat_points = query_points.view(-1, 4)
-        return self.fine_model(flat_points)['inferences']
+        return self.fine_model(query_points.view(-1, 4))['inferences']
 
     def raw2outputs(self, **kwargs):
         raise NotImplementedError("This method should be implemented in a subclass")
 
 
 def cumprod_exclusive(tensor: torch.Tensor) -> torch.Tensor:
-    """base_tracing.py:135-156 (kept for API compatibility; the fused kernel uses a per-wavefront scan)."""
-    cumprod = torch.cumprod(tensor, -1)
-    cumprod = torch.roll(cumprod, 1, -1)
-    cumprod[..., 0] = 1.
-    return cumprod
+    """Exclusive cumulative product along the last dimension: ``out[..., i] = prod(tensor[..., :i])``, ``out[..., 0] = 1``
+    (base_tracing.py:135-156; same values: the inclusive products shifted by one).  Kept for callers of the module API;
+    the fused kernels use a per-wavefront scan."""
+    inclusive = torch.cumprod(tensor, -1)
+    return torch.cat([torch.ones_like(inclusive[..., :1]), inclusive[..., :-1]], dim=-1)

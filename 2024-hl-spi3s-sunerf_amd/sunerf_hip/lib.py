@@ -69,7 +69,7 @@ _SIGNATURES = {
     'sunerf_clip_adam_step': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int64, ctypes.c_double,
                                               ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_float,
                                               ctypes.c_float, ctypes.c_int64, c_f32p, c_f32p, c_void, ctypes.c_size_t,
-                                              c_void]),
+                                              c_void, c_void]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -92,7 +92,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.sunerf_abi_version() != 2:
+        if lib.sunerf_abi_version() != 3:
             raise SunerfHipError('libsunerf_hip.so ABI version mismatch')
         _lib = lib
     return _lib
@@ -109,3 +109,13 @@ def check(status, what):
     if status in (-1, -2, -3):
         raise ValueError(f'{what}: {_ERRORS[status]}')
     raise SunerfHipError(f'{what}: HIP error {status}')
+
+
+def call(device, name, *args):
+    """Runs C-ABI entry point ``name`` with ``device`` current (the library sizes its grids from hipGetDevice() and a
+    kernel can only be launched into a stream of the current device: a module on cuda:1 while cuda:0 is current would
+    otherwise fail or use the wrong CU count) and raises on a non-zero status."""
+    fn = getattr(load(), name)
+    with torch.cuda.device(device):
+        status = fn(*args)
+    check(status, name)

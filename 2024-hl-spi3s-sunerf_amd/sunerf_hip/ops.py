@@ -15,18 +15,33 @@ SAMPLER_SPHERICAL = 1
 SUPPORTED_D_FILTER = (64, 128, 256, 512)
 TRAINABLE_D_FILTER = (64, 128, 256, 512)
 PRECISION_FAST, PRECISION_EXACT, PRECISION_HALF = 0, 1, 2     # include/sunerf_hip.h: SUNERF_PRECISION_*
+PRECISION_AUTO = -1           # host-side policy (not a kernel mode): FAST while a probe shows it inside the gate, else EXACT
+PRECISION_NAMES = {PRECISION_FAST: 'fast', PRECISION_EXACT: 'exact', PRECISION_HALF: 'half', PRECISION_AUTO: 'auto'}
+
+# AUTO policy.  FAST (fp16 head + two fp8 correction products) behaves like arithmetic with ~58x the rounding noise of the
+# fp32 reference, EXACT (three fp16 products) like ~7x (tools/precision_scan.py): both are far inside
+# the north-star gate (1e-4 relative) for freshly initialised and for trained networks, but the noise of ANY arithmetic
+# -- the reference's included -- is amplified by the network's conditioning, and with all hidden weights x 4 FAST leaves
+# the gate while EXACT stays inside.  So the mode is chosen by MEASUREMENT: every PROBE_EVERY-th parameter version (and the
+# first) the first PROBE_RAYS rays of the render call at hand are rendered in both modes and compared in gate units,
+#     max_ray |fast - exact| / (1e-4 |exact| + 1e-6 max|exact|)      over image, height_map, absorption_map,
+# FAST is kept while that stays below PROBE_LIMIT (the margin covers EXACT's own error and rays outside the probe).
+PROBE_EVERY = 64
+PROBE_RAYS = 64
+PROBE_LIMIT = 0.35
 
 
 def default_precision(d_filter: int) -> int:
-    """Forward arithmetic of newly packed models: ``SUNERF_FORWARD_PRECISION`` = ``fast`` (default: fp16 head product + two
-    block-scaled fp8 correction products, fp32-class results), ``exact`` (three fp16 products per term) or ``half``
-    (opt-in: single fp16 operands -- the bf16-class arithmetic of BASELINE config 3; NOT within 1e-4 of
-    the fp32 reference)."""
+    """Forward arithmetic of newly packed models: ``SUNERF_FORWARD_PRECISION`` = ``auto`` (default: ``fast`` guarded by the
+    probe above), ``fast`` (fp16 head product + two block-scaled fp8 correction products), ``exact`` (three fp16
+    products per term) or ``half`` (opt-in: single fp16 operands -- the bf16-class arithmetic of BASELINE config 3; NOT
+    within 1e-4 of the fp32 reference)."""
     import os
-    mode = os.environ.get('SUNERF_FORWARD_PRECISION', 'fast').lower()
-    if mode not in ('fast', 'exact', 'half'):
-        raise ValueError(f"SUNERF_FORWARD_PRECISION must be 'fast', 'exact' or 'half', not {mode!r}")
-    return {'fast': PRECISION_FAST, 'exact': PRECISION_EXACT, 'half': PRECISION_HALF}[mode]
+    mode = os.environ.get('SUNERF_FORWARD_PRECISION', 'auto').lower()
+    names = {v: k for k, v in PRECISION_NAMES.items()}
+    if mode not in names:
+        raise ValueError(f"SUNERF_FORWARD_PRECISION must be one of {sorted(names)}, not {mode!r}")
+    return names[mode]
 
 
 _workspaces = {}                        # (device, stream) -> scratch of the d_filter = 512 render kernel
@@ -60,7 +75,12 @@ class PackedMLP:
     def __init__(self, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], precision: Optional[int] = None):
         self.n_linear = len(weights)
         self.d_filter = int(weights[0].shape[0])
-        self.precision = default_precision(self.d_filter) if precision is None else int(precision)
+        precision = default_precision(self.d_filter) if precision is None else int(precision)
+        self.auto = precision == PRECISION_AUTO
+        self.precision = PRECISION_FAST if self.auto else precision          # the kernel mode of `buffer`
+        self.probe_due = self.auto
+        self.last_probe = None            # gate units measured by the last probe (AUTO only)
+        self._versions_since_probe = 0
         self.d_out = int(weights[-1].shape[0])
         if self.d_filter not in SUPPORTED_D_FILTER:
             raise ValueError(f'd_filter={self.d_filter} is not in the compiled set {SUPPORTED_D_FILTER}')
@@ -87,11 +107,58 @@ class PackedMLP:
             bs.append(_dev(b.detach(), f'bias[{i}]', (d_o,)))
         W = (ctypes.c_void_p * self.n_linear)(*[w.data_ptr() for w in ws])
         B = (ctypes.c_void_p * self.n_linear)(*[b.data_ptr() for b in bs])
-        st = lib.sunerf_pack_mlp(W, B, self.n_linear, self.d_filter, self.d_out, self.precision, _ptr(self.buffer),
-                                 _stream(self.device))
-        _l.check(st, 'sunerf_pack_mlp')
+        _l.call(self.device, 'sunerf_pack_mlp', W, B, self.n_linear, self.d_filter, self.d_out, self.precision,
+                _ptr(self.buffer), _stream(self.device))
         self._keepalive = (ws, bs)   # until the pack kernel has run on the stream
         self._t_valid = False
+        if self.auto:
+            self._versions_since_probe += 1
+            if self._versions_since_probe >= PROBE_EVERY:
+                self.probe_due = True
+
+    def _pack_into(self, buffer: torch.Tensor, precision: int):
+        ws, bs = self._keepalive
+        W = (ctypes.c_void_p * self.n_linear)(*[w.data_ptr() for w in ws])
+        B = (ctypes.c_void_p * self.n_linear)(*[b.data_ptr() for b in bs])
+        _l.call(self.device, 'sunerf_pack_mlp', W, B, self.n_linear, self.d_filter, self.d_out, precision, _ptr(buffer),
+                _stream(self.device))
+
+    def probe(self, rays_o, rays_d, times, z_vals, reg_radius: float) -> float:
+        """AUTO: renders the first PROBE_RAYS rays in both arithmetics, keeps FAST if it is inside the gate with margin,
+        switches this image to EXACT otherwise (and back when a later probe allows it).  One 4-byte device -> host read
+        per PROBE_EVERY parameter versions.  Returns the measured gate units."""
+        n = min(PROBE_RAYS, rays_o.shape[0])
+        self.probe_due = False
+        self._versions_since_probe = 0
+        if n == 0:
+            return 0.0
+        if getattr(self, '_alt_buffer', None) is None:
+            self._alt_buffer = torch.empty_like(self.buffer)
+        other = PRECISION_EXACT if self.precision == PRECISION_FAST else PRECISION_FAST
+        self._pack_into(self._alt_buffer, other)
+        views = {self.precision: self.buffer, other: self._alt_buffer}
+        outs = {}
+        for mode, buf in views.items():
+            shadow = object.__new__(PackedMLP)
+            shadow.__dict__.update(self.__dict__)
+            shadow.buffer, shadow.precision, shadow.auto = buf, mode, False
+            outs[mode] = emission_render_fwd(shadow, rays_o[:n], rays_d[:n], times.reshape(-1)[:n], z_vals[:n], reg_radius,
+                                             want_epilogues=True)
+        units = torch.zeros((), dtype=torch.float32, device=self.device)
+        for k in ('image', 'height_map', 'absorption_map'):
+            f, e = outs[PRECISION_FAST][k].reshape(-1), outs[PRECISION_EXACT][k].reshape(-1)
+            # absorption_map = sum(1 - a): the reference forms 1 - a in fp32, i.e. with 2^-24 absolute noise per sample
+            floor = z_vals.shape[1] * 6e-8 if k == 'absorption_map' else 0.0
+            units = torch.maximum(units, ((f - e).abs() / (1e-4 * e.abs() + 1e-6 * e.abs().max() + floor)).max())
+        units = float(units.item())
+        if not (units == units):            # NaN: non-finite outputs in either mode -- leave the decision to the finite check
+            units = float('inf')
+        self.last_probe = units
+        want = PRECISION_FAST if units <= PROBE_LIMIT else PRECISION_EXACT
+        if want != self.precision:
+            self.buffer, self._alt_buffer = self._alt_buffer, self.buffer
+            self.precision = want
+        return units
 
     def transposed(self) -> torch.Tensor:
         """fp16 W^T image consumed by sunerf_mlp_dgrad (packed lazily, once per parameter version)."""
@@ -102,9 +169,8 @@ class PackedMLP:
         if not self._t_valid:
             ws = self._keepalive[0]
             W = (ctypes.c_void_p * self.n_linear)(*[w.data_ptr() for w in ws])
-            st = lib.sunerf_pack_mlp_t(W, self.n_linear, self.d_filter, self.d_out, _ptr(self.buffer_t),
-                                       _stream(self.device))
-            _l.check(st, 'sunerf_pack_mlp_t')
+            _l.call(self.device, 'sunerf_pack_mlp_t', W, self.n_linear, self.d_filter, self.d_out,
+                    _ptr(self.buffer_t), _stream(self.device))
             self._t_valid = True
         return self.buffer_t
 
@@ -120,9 +186,8 @@ def sample_z(kind: int, rays_o, rays_d, t_vals, distance: float, solar_R: float,
     if t_rand is not None:
         t_rand = _dev(t_rand, 't_rand', (n, s))
     z = torch.empty(n, s, dtype=torch.float32, device=rays_o.device)
-    st = lib.sunerf_sample_z(kind, _ptr(rays_o), _ptr(rays_d), _ptr(t_vals), _ptr(t_rand), n, s,
-                             float(distance), float(solar_R), _ptr(z), _stream(rays_o.device))
-    _l.check(st, 'sunerf_sample_z')
+    _l.call(rays_o.device, 'sunerf_sample_z', kind, _ptr(rays_o), _ptr(rays_d), _ptr(t_vals), _ptr(t_rand), n, s,
+            float(distance), float(solar_R), _ptr(z), _stream(rays_o.device))
     return z
 
 
@@ -140,6 +205,8 @@ def emission_render_fwd(packed: PackedMLP, rays_o, rays_d, times, z_vals, reg_ra
     z_vals = _dev(z_vals, 'z_vals', (n, s))
     if packed.device != dev:
         raise _l.SunerfHipError('packed weights and rays are on different devices')
+    if packed.auto and packed.probe_due:
+        packed.probe(rays_o, rays_d, times, z_vals, reg_radius)
     f32 = dict(dtype=torch.float32, device=dev)
     out = {'image': torch.empty(n, 1, **f32), 'weights': torch.empty(n, s, **f32),
            'absorption': torch.empty(n, s, **f32)}
@@ -162,11 +229,10 @@ def emission_render_fwd(packed: PackedMLP, rays_o, rays_d, times, z_vals, reg_ra
     hm = am = reg = None
     if want_epilogues:
         hm, am, reg = torch.empty(n, **f32), torch.empty(n, **f32), torch.empty(n, s, **f32)
-    st = lib.sunerf_emission_render_fwd(_ptr(packed.buffer), packed.d_filter, packed.n_linear, packed.precision, _ptr(rays_o),
-                                        _ptr(rays_d), _ptr(times), _ptr(z_vals), n, s, _ptr(out['image']),
-                                        _ptr(out['weights']), _ptr(out['absorption']), _ptr(raw), _ptr(hm), _ptr(am),
-                                        _ptr(reg), float(reg_radius), _ptr(stash), _ptr(ws), ws_bytes, _stream(dev))
-    _l.check(st, 'sunerf_emission_render_fwd')
+    _l.call(dev, 'sunerf_emission_render_fwd', _ptr(packed.buffer), packed.d_filter, packed.n_linear,
+            packed.precision, _ptr(rays_o), _ptr(rays_d), _ptr(times), _ptr(z_vals), n, s, _ptr(out['image']),
+            _ptr(out['weights']), _ptr(out['absorption']), _ptr(raw), _ptr(hm), _ptr(am), _ptr(reg),
+            float(reg_radius), _ptr(stash), _ptr(ws), ws_bytes, _stream(dev))
     if want_raw:
         out['raw'] = raw
     if training:
@@ -187,9 +253,8 @@ def hier_resample(z_vals, weights, u: torch.Tensor) -> Tuple[torch.Tensor, torch
     u = _dev(u, 'u', (n, sf) if per_ray else (sf,))
     new_z = torch.empty(n, sf, dtype=torch.float32, device=z_vals.device)
     z_comb = torch.empty(n, sc + sf, dtype=torch.float32, device=z_vals.device)
-    st = lib.sunerf_hier_resample(_ptr(z_vals), _ptr(weights), _ptr(u), per_ray, n, sc, sf, _ptr(new_z),
-                                  _ptr(z_comb), _stream(z_vals.device))
-    _l.check(st, 'sunerf_hier_resample')
+    _l.call(z_vals.device, 'sunerf_hier_resample', _ptr(z_vals), _ptr(weights), _ptr(u), per_ray, n, sc, sf,
+            _ptr(new_z), _ptr(z_comb), _stream(z_vals.device))
     return new_z, z_comb
 
 
@@ -221,9 +286,8 @@ def emission_render_bwd(packed: PackedMLP, rays_o, rays_d, z_vals, raw, stash, g
     g_raw = torch.empty(n, s, 2, dtype=torch.float32, device=dev)
     absmax = torch.empty(1, dtype=torch.int32, device=dev)
     stream = _stream(dev)
-    st = lib.sunerf_emission_integral_bwd(_ptr(raw), _ptr(z_vals), _ptr(rays_o), _ptr(rays_d), _ptr(g_image), _ptr(g_reg),
-                                          float(g_reg_const), float(reg_radius), n, s, _ptr(g_raw), _ptr(absmax), stream)
-    _l.check(st, 'sunerf_emission_integral_bwd')
+    _l.call(dev, 'sunerf_emission_integral_bwd', _ptr(raw), _ptr(z_vals), _ptr(rays_o), _ptr(rays_d), _ptr(g_image),
+            _ptr(g_reg), float(g_reg_const), float(reg_radius), n, s, _ptr(g_raw), _ptr(absmax), stream)
     mlp_backward(packed, g_raw, absmax, stash, grad_weights, grad_biases, accumulate)
     return g_raw
 
@@ -238,9 +302,8 @@ def mlp_backward(packed: PackedMLP, g_raw, absmax, stash, grad_weights: Sequence
     D, nl = packed.d_filter, packed.n_linear
     stream = _stream(dev)
     dz = torch.empty(lib.sunerf_dz_stash_bytes(n, s, D, nl), dtype=torch.uint8, device=dev)
-    st = lib.sunerf_mlp_dgrad(_ptr(packed.transposed()), D, nl, _ptr(g_raw), _ptr(absmax), _ptr(stash), _ptr(dz), n, s,
-                              stream)
-    _l.check(st, 'sunerf_mlp_dgrad')
+    _l.call(dev, 'sunerf_mlp_dgrad', _ptr(packed.transposed()), D, nl, _ptr(g_raw), _ptr(absmax), _ptr(stash),
+            _ptr(dz), n, s, stream)
     split = wgrad_split(nl, torch.cuda.get_device_properties(dev).multi_processor_count, D)
     ws = torch.empty(lib.sunerf_wgrad_workspace_bytes(packed.d_filter, nl, split), dtype=torch.uint8, device=dev)
     for i, (gw, gb) in enumerate(zip(grad_weights, grad_biases)):
@@ -250,9 +313,8 @@ def mlp_backward(packed: PackedMLP, g_raw, absmax, stash, grad_weights: Sequence
             raise ValueError(f'grad buffer {i} has the wrong shape / layout')
     GW = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grad_weights])
     GB = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grad_biases])
-    st = lib.sunerf_mlp_wgrad(D, nl, packed.d_out, _ptr(stash), _ptr(dz), _ptr(g_raw), _ptr(absmax), n, s, _ptr(ws),
-                              split, GW, GB, int(accumulate), stream)
-    _l.check(st, 'sunerf_mlp_wgrad')
+    _l.call(dev, 'sunerf_mlp_wgrad', D, nl, packed.d_out, _ptr(stash), _ptr(dz), _ptr(g_raw), _ptr(absmax), n, s,
+            _ptr(ws), split, GW, GB, int(accumulate), stream)
 
 
 AIA_WAVELENGTHS = (94, 131, 171, 193, 211, 304, 335)
@@ -275,12 +337,10 @@ def dt_integral_fwd(raw, z_vals, rays_o, rays_d, wavelengths, table_logt, table_
     hm = am = reg = None
     if want_epilogues:
         hm, am, reg = torch.empty(n, **f32), torch.empty(n, **f32), torch.empty(n, s, **f32)
-    st = lib.sunerf_dt_integral_fwd(_ptr(raw), _ptr(z_vals), _ptr(rays_o), _ptr(rays_d), _ptr(wavelengths), w,
-                                    _ptr(table_logt), _ptr(table_resp), _ptr(log_abs), _ptr(vol_c), float(base_log_density),
-                                    float(base_log_temperature), float(pixel_intensity_factor), float(reg_radius), n, s,
-                                    _ptr(out['image']), _ptr(out['weights']), _ptr(out['reg_q']), _ptr(hm), _ptr(am), _ptr(reg),
-                                    _stream(dev))
-    _l.check(st, 'sunerf_dt_integral_fwd')
+    _l.call(dev, 'sunerf_dt_integral_fwd', _ptr(raw), _ptr(z_vals), _ptr(rays_o), _ptr(rays_d), _ptr(wavelengths), w,
+            _ptr(table_logt), _ptr(table_resp), _ptr(log_abs), _ptr(vol_c), float(base_log_density),
+            float(base_log_temperature), float(pixel_intensity_factor), float(reg_radius), n, s, _ptr(out['image']),
+            _ptr(out['weights']), _ptr(out['reg_q']), _ptr(hm), _ptr(am), _ptr(reg), _stream(dev))
     if want_epilogues:
         out.update(height_map=hm, absorption_map=am, regularization=reg)
     return out
@@ -292,9 +352,8 @@ def simple_star_field(rays_o, rays_d, z_vals, rho_0: float, h0: float, T0: float
     n, s = z_vals.shape
     rays_o = _dev(rays_o, 'rays_o', (n, 3)); rays_d = _dev(rays_d, 'rays_d', (n, 3)); z_vals = _dev(z_vals, 'z_vals', (n, s))
     raw = torch.empty(n, s, 2, dtype=torch.float32, device=z_vals.device)
-    st = lib.sunerf_simple_star_field(_ptr(rays_o), _ptr(rays_d), _ptr(z_vals), n, s, float(rho_0), float(h0), float(T0),
-                                      float(Rs), float(t_photosphere), _ptr(raw), _stream(z_vals.device))
-    _l.check(st, 'sunerf_simple_star_field')
+    _l.call(z_vals.device, 'sunerf_simple_star_field', _ptr(rays_o), _ptr(rays_d), _ptr(z_vals), n, s, float(rho_0),
+            float(h0), float(T0), float(Rs), float(t_photosphere), _ptr(raw), _stream(z_vals.device))
     return raw
 
 
@@ -316,9 +375,8 @@ def dt_integral_bwd(raw, z_vals, rays_o, rays_d, wavelengths, table_logt, table_
     g_raw = torch.empty(n, s, 2, **f32)
     g_la, g_vc = torch.empty(7, **f32), torch.empty(1, **f32)
     absmax = torch.empty(1, dtype=torch.int32, device=dev)
-    st = lib.sunerf_dt_integral_bwd(_ptr(raw), _ptr(z_vals), _ptr(rays_o), _ptr(rays_d), _ptr(wavelengths), w,
-                                    _ptr(table_logt), _ptr(table_resp), _ptr(log_abs), _ptr(vol_c), float(base_log_density),
-                                    float(base_log_temperature), float(pixel_intensity_factor), float(reg_radius), n, s,
-                                    _ptr(g_image), _ptr(g_reg), _ptr(g_raw), _ptr(g_la), _ptr(g_vc), _ptr(absmax), _stream(dev))
-    _l.check(st, 'sunerf_dt_integral_bwd')
+    _l.call(dev, 'sunerf_dt_integral_bwd', _ptr(raw), _ptr(z_vals), _ptr(rays_o), _ptr(rays_d), _ptr(wavelengths), w,
+            _ptr(table_logt), _ptr(table_resp), _ptr(log_abs), _ptr(vol_c), float(base_log_density),
+            float(base_log_temperature), float(pixel_intensity_factor), float(reg_radius), n, s, _ptr(g_image),
+            _ptr(g_reg), _ptr(g_raw), _ptr(g_la), _ptr(g_vc), _ptr(absmax), _stream(dev))
     return g_raw, g_la, g_vc, absmax

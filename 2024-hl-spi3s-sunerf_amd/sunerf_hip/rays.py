@@ -62,10 +62,8 @@ def grid_rays(tx: torch.Tensor, ty: torch.Tensor, c2w: torch.Tensor, pix_begin: 
     rays_d = torch.empty(n_pix, 3, dtype=torch.float32, device=dev)
     times = torch.empty(n_pix, 1, dtype=torch.float32, device=dev) if time is not None else None
     m = (ctypes.c_float * 12)(*[float(v) for v in c2w[:3, :4].reshape(-1).tolist()])
-    st = _l.load().sunerf_observer_rays(_ptr(tx), _ptr(ty), 1 if per_pixel else 0, width, pix_begin, n_pix, m,
-                                        float(time) if time is not None else 0.0, _ptr(rays_o), _ptr(rays_d), _ptr(times),
-                                        _stream(dev))
-    _l.check(st, 'sunerf_observer_rays')
+    _l.call(dev, 'sunerf_observer_rays', _ptr(tx), _ptr(ty), 1 if per_pixel else 0, width, pix_begin, n_pix, m,
+            float(time) if time is not None else 0.0, _ptr(rays_o), _ptr(rays_d), _ptr(times), _stream(dev))
     return (rays_o, rays_d) if time is None else (rays_o, rays_d, times)
 
 

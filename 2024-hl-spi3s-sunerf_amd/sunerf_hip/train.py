@@ -45,11 +45,10 @@ class _TrainingLoss(torch.autograd.Function):
         stats = torch.empty(8, dtype=torch.float32, device=dev)
         ws = _workspace(dev)
         scaling = cfg['scaling']
-        st = lib.sunerf_training_loss(_ptr(coarse_c), _ptr(fine_c), _ptr(target_c), n, _ptr(reg_c), n_reg, ptrs, sizes,
-                                      len(extras), 1 if scaling else 0, scaling[0] if scaling else 1.0,
-                                      scaling[1] if scaling else 1.0, cfg['lambda_image'], cfg['lambda_regularization'],
-                                      _ptr(g_coarse), _ptr(g_fine), _ptr(stats), _ptr(ws), ws.numel(), _stream(dev))
-        _l.check(st, 'sunerf_training_loss')
+        _l.call(dev, 'sunerf_training_loss', _ptr(coarse_c), _ptr(fine_c), _ptr(target_c), n, _ptr(reg_c), n_reg,
+                ptrs, sizes, len(extras), 1 if scaling else 0, scaling[0] if scaling else 1.0, scaling[1] if scaling
+                else 1.0, cfg['lambda_image'], cfg['lambda_regularization'], _ptr(g_coarse), _ptr(g_fine),
+                _ptr(stats), _ptr(ws), ws.numel(), _stream(dev))
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(g_coarse, g_fine)
         ctx.reg_shape = None if reg is None else tuple(reg.shape)
@@ -94,7 +93,13 @@ class ClipAdam(torch.optim.Optimizer):
     On construction all parameters are moved into one flat fp32 buffer (``p.data`` become views of it), ``p.grad`` into a
     second one (so backward kernels write straight into the buffer that is all-reduced), and the two moment buffers are
     flat as well.  ``step()`` = optional sum all-reduce over ``group`` -> ||g / world|| -> clip -> Adam, two kernels, and
-    no ``.item()``: the learning rate and bias corrections are host scalars, the norm stays on the device.
+    no ``.item()``: the learning rate is a host scalar, the norm, the step counter and the skip decision stay on the device.
+
+    Rank lock-step (the reference asserts on NaN / Inf, sunerf.py:105-107): the gradient bucket has ONE extra
+    element at its tail that carries this rank's non-finite-output count of the step (``skip_if_positive``).  The same
+    all-reduce that sums the gradients sums it, so every rank sees the global count and takes the same decision; a
+    non-finite gradient norm (computed after the reduce) skips as well.  A skipped step leaves parameters, moments AND the
+    bias-correction step counter untouched.
 
     ``param_groups`` carries ``lr`` / ``betas`` / ``eps`` like torch's Adam, so ``ExponentialLR`` (sunerf.py:32) works
     unchanged.  ``max_norm=None`` leaves clipping to the caller (e.g. Lightning's ``gradient_clip_val``)."""
@@ -106,6 +111,7 @@ class ClipAdam(torch.optim.Optimizer):
             raise ValueError('ClipAdam keeps one flat buffer: a single parameter group')
         self.max_norm = max_norm
         self.group = group
+        self.reduce_single_rank = False     # tests: issue the collective even in a one-rank group (exercises RCCL on one GPU)
         self._params = [p for p in self.param_groups[0]['params'] if p.requires_grad]
         if not self._params:
             raise ValueError('no trainable parameters')
@@ -113,12 +119,15 @@ class ClipAdam(torch.optim.Optimizer):
         if dev.type != 'cuda' or any(p.device != dev or p.dtype != torch.float32 for p in self._params):
             raise _l.SunerfHipError('ClipAdam needs float32 parameters on one ROCm device')
         n = sum(p.numel() for p in self._params)
+        self.n_params = n
         self.flat_params = torch.empty(n, dtype=torch.float32, device=dev)
-        self.flat_grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.bucket = torch.zeros(n + 1, dtype=torch.float32, device=dev)     # gradients + the non-finite count
+        self.flat_grads = self.bucket[:n]
+        self.nonfinite = self.bucket[n:]
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.norm = torch.zeros(2, dtype=torch.float32, device=dev)      # total gradient norm, clip coefficient
-        self.step_count = 0
+        self.norm = torch.zeros(4, dtype=torch.float32, device=dev)      # total gradient norm, clip coefficient, skipped, 0
+        self.applied_steps = torch.zeros(1, dtype=torch.int64, device=dev)
         self._grad_views = []
         off = 0
         for p in self._params:
@@ -133,10 +142,15 @@ class ClipAdam(torch.optim.Optimizer):
                              'exp_avg_sq': self.exp_avg_sq[off:off + k].view_as(p)}
             off += k
 
+    @property
+    def step_count(self) -> int:
+        """Number of updates actually applied (one device -> host read; not used inside the step)."""
+        return int(self.applied_steps.item())
+
     def zero_grad(self, set_to_none: bool = False):
-        """Zeroes the flat gradient buffer and re-attaches the views (``set_to_none`` is ignored: the backward kernels
+        """Zeroes the flat gradient bucket and re-attaches the views (``set_to_none`` is ignored: the backward kernels
         and the all-reduce work in place on the bucket)."""
-        self.flat_grads.zero_()
+        self.bucket.zero_()
         for p, gv in zip(self._params, self._grad_views):
             p.grad = gv
 
@@ -151,28 +165,37 @@ class ClipAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, skip_if_positive: Optional[torch.Tensor] = None):
         loss = closure() if closure is not None else None
-        lib = _l.load()
         self._collect()
+        if skip_if_positive is not None:
+            self.nonfinite.copy_(skip_if_positive.reshape(1))
+        else:
+            self.nonfinite.zero_()
         world = 1
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if dist.is_available() and dist.is_initialized():
             world = dist.get_world_size(self.group)
-            dist.all_reduce(self.flat_grads, op=dist.ReduceOp.SUM, group=self.group)
+            if world > 1 or self.reduce_single_rank:
+                dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
         g = self.param_groups[0]
-        self.step_count += 1
         dev = self.flat_params.device
         ws = _workspace(dev)
         max_norm = float(self.max_norm) if self.max_norm else 0.0
-        st = lib.sunerf_clip_adam_step(_ptr(self.flat_params), _ptr(self.flat_grads), _ptr(self.exp_avg),
-                                       _ptr(self.exp_avg_sq), self.flat_params.numel(), float(g['lr']),
-                                       float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), max_norm, 1.0 / world,
-                                       self.step_count, _ptr(skip_if_positive), _ptr(self.norm), _ptr(ws), ws.numel(),
-                                       _stream(dev))
-        _l.check(st, 'sunerf_clip_adam_step')
-        for p in self._params:
-            self.state[p]['step'] += 1
+        _l.call(dev, 'sunerf_clip_adam_step', _ptr(self.flat_params), _ptr(self.flat_grads), _ptr(self.exp_avg),
+                _ptr(self.exp_avg_sq), self.n_params, float(g['lr']), float(g['betas'][0]), float(g['betas'][1]),
+                float(g['eps']), max_norm, 1.0 / world, 0, _ptr(self.nonfinite), _ptr(self.norm), _ptr(ws), ws.numel(),
+                _ptr(self.applied_steps), _stream(dev))
         # the kernels wrote through raw pointers: tell autograd / the packed-weights cache that the values changed
         torch.autograd.graph.increment_version(self._params)
         return loss
+
+    def skipped_last_step(self) -> bool:
+        """True when the last ``step()`` was skipped on all ranks (one 4-byte read)."""
+        return bool(self.norm[2].item() > 0)
+
+    def state_dict(self):
+        steps = float(self.step_count)
+        for p in self._params:
+            self.state[p]['step'] = torch.tensor(steps)
+        return super().state_dict()
 
     def load_state_dict(self, state_dict):
         """Accepts a ``torch.optim.Adam`` state dict (reference checkpoints): moments are copied into the flat buffers."""
@@ -194,4 +217,4 @@ class ClipAdam(torch.optim.Optimizer):
         if steps:
             if len(set(steps)) != 1:
                 raise ValueError('parameters with different step counts cannot share the fused bias correction')
-            self.step_count = steps[0]
+            self.applied_steps.fill_(steps[0])

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUNERF_ABI_VERSION 2
+#define SUNERF_ABI_VERSION 3
 
 #define SUNERF_E_BADARG   (-1)   /* null pointer / non-positive size                               */
 #define SUNERF_E_UNSUPPORTED (-2) /* d_filter / n_layers / sample count outside the compiled set     */
@@ -217,9 +217,16 @@ int sunerf_observer_rays(const double* tx, const double* ty, int per_pixel, int 
  * run_emission.py:72) followed by torch.optim.Adam.step() (sunerf.py:31) on ONE flat fp32 buffer:
  *   g = grads * grad_scale (1 / world size after a sum all-reduce); total = ||g||_2; g *= min(1, max_norm / (total + 1e-6));
  *   m += (1 - beta1)(g - m); v = beta2 v + (1 - beta2) g g; p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
- *   max_norm <= 0 disables clipping (norm_out / workspace may then be NULL); step counts from 1;
- *   skip_if_positive: optional device float (e.g. stats + 5); a value > 0 leaves params and moments untouched;
- *   norm_out (2 floats, device): total norm, clip coefficient.  grads holds the scaled, clipped gradient afterwards.
+ *   max_norm <= 0 disables clipping; step counts from 1.
+ *   skip_if_positive: optional device float -- the number of non-finite outputs of this step summed over ALL ranks (the
+ *     caller carries it as one extra element at the tail of the all-reduced gradient bucket); a value > 0
+ *     leaves params and moments untouched, and so does a non-finite gradient norm: every rank takes the same decision
+ *     because both inputs are results of the all-reduce (the reference asserts instead, sunerf.py:105-107).
+ *   norm_out (4 floats, device): total norm, clip coefficient, skipped (0 / 1), 0.  grads holds the scaled, clipped
+ *     gradient afterwards.  norm_out / workspace may be NULL only with max_norm <= 0 and step_counter == NULL (then there
+ *     is no norm pass and only skip_if_positive can skip).
+ *   step_counter: optional device int64 -- number of APPLIED updates.  When given it is authoritative (`step` is ignored):
+ *     the update uses *step_counter + 1 for the bias corrections and advances the counter only if it is not skipped.
  * ---------------------------------------------------------------------------------------------------------- */
 size_t sunerf_train_workspace_bytes(void);
 int sunerf_training_loss(const float* coarse_image, const float* fine_image, const float* target_image, int64_t n,
@@ -230,7 +237,7 @@ int sunerf_training_loss(const float* coarse_image, const float* fine_image, con
 int sunerf_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
                           double beta1, double beta2, double eps, float max_norm, float grad_scale, int64_t step,
                           const float* skip_if_positive, float* norm_out, void* workspace, size_t workspace_bytes,
-                          void* stream);
+                          void* step_counter, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Analytic field of SimpleStar: replaces SimpleStar.forward, sunerf/model/stellar_model.py:53-102,

@@ -111,3 +111,50 @@ def test_backward_with_fewer_chunks_than_workgroups(ops):
     torch.cuda.synchronize()
     for (rW, rb), W in zip(ref_grads, gW):
         assert ((W.cpu() - rW).norm() / rW.norm()).item() < 2e-3
+
+
+@pytest.mark.parametrize('scale', [2.0, 4.0])
+def test_backward_with_scaled_up_hidden_weights(ops, scale):
+    """the backward had only been run on weights at or below their initial scale.  An 8 x 256 network whose hidden
+    layers amplify (all hidden weights x 2 / x 4: the data gradient grows by up to 2^8 from the output to the first layer)
+    against the oracle's autograd, same 1e-3 per tensor; EXACT forward so that only the backward arithmetic is on trial."""
+    params, o, d, t, z = _case(256, 8, 64)
+    params = [(W * scale, b) if 0 < i < len(params) - 1 else (W, b) for i, (W, b) in enumerate(params)]
+    n = o.shape[0]
+    g_image = torch.randn(n) * 1e-3
+    ref_out, ref_grads, ref_graw = _oracle_grads(params, o, d, t, z, g_image, 2e-5)
+    dev = torch.device('cuda')
+    Ws, bs = [W.to(dev) for W, _ in params], [b.to(dev) for _, b in params]
+    packed = ops.PackedMLP(Ws, bs, precision=ops.PRECISION_EXACT)
+    fwd = ops.emission_render_fwd(packed, o.to(dev), d.to(dev), t.to(dev), z.to(dev), reg_radius=1.2, training=True)
+    gW, gb = [torch.full_like(W, float('nan')) for W in Ws], [torch.full_like(b, float('nan')) for b in bs]
+    ops.emission_render_bwd(packed, o.to(dev), d.to(dev), z.to(dev), fwd['raw'], fwd['stash'], g_image.to(dev), None, 2e-5, 1.2,
+                            gW, gb)
+    torch.cuda.synchronize()
+    growth = ref_grads[0][1].abs().max() / ref_grads[-1][1].abs().max()      # |db_0| / |db_out|: the chain's amplification
+    worst = 0.
+    for i, ((rW, rb), W, b) in enumerate(zip(ref_grads, gW, gb)):
+        assert torch.isfinite(W).all() and torch.isfinite(b).all(), i
+        eW, eb = ((W.cpu() - rW).norm() / rW.norm()).item(), ((b.cpu() - rb).norm() / rb.norm()).item()
+        worst = max(worst, eW, eb)
+        # the oracle's own fp32 autograd is ill-conditioned at x 4 (its forward noise is 0.1 gate units there): 2e-3
+        assert eW < (1e-3 if scale <= 2 else 2e-3) and eb < (1e-3 if scale <= 2 else 2e-3), (i, eW, eb)
+    print(f'hidden x {scale:g}: gradient growth out -> in {growth.item():.1f} x, worst relative L2 error {worst:.2e}')
+
+
+def test_backward_saturates_instead_of_overflowing(ops):
+    """Hidden weights x 16: the data gradient outgrows fp16 even with the 2^12 head-room -- the dZ fragments saturate at
+    +-65504, the weight gradients stay finite (bent, but the step survives; an overflow to infinity used to turn every
+    weight gradient into NaN and, through the clip coefficient, every parameter)."""
+    params, o, d, t, z = _case(256, 8, 32, n_side=4)
+    params = [(W * 16., b) if 0 < i < len(params) - 1 else (W, b) for i, (W, b) in enumerate(params)]
+    dev = torch.device('cuda')
+    Ws, bs = [W.to(dev) for W, _ in params], [b.to(dev) for _, b in params]
+    packed = ops.PackedMLP(Ws, bs, precision=ops.PRECISION_EXACT)
+    fwd = ops.emission_render_fwd(packed, o.to(dev), d.to(dev), t.to(dev), z.to(dev), reg_radius=1.2, training=True)
+    gW, gb = [torch.zeros_like(W) for W in Ws], [torch.zeros_like(b) for b in bs]
+    ops.emission_render_bwd(packed, o.to(dev), d.to(dev), z.to(dev), fwd['raw'], fwd['stash'],
+                            torch.ones(o.shape[0], device=dev), None, 0.0, 1.2, gW, gb)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(g).all() for g in gW + gb)
+    assert gW[1].abs().max().item() > 0

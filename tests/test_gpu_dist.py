@@ -35,10 +35,11 @@ def _batch():
     return o, d, torch.rand(64, 1, generator=gen).cuda(), torch.rand(64, 1, generator=gen).cuda()
 
 
-def _train(rendering, o, d, t, target, group_active):
+def _train(rendering, o, d, t, target, group_active, steps=STEPS):
     from sunerf_hip.train import ClipAdam, training_loss
     opt = ClipAdam(rendering.parameters(), lr=1e-3, max_norm=0.5)
-    for _ in range(STEPS):
+    opt.reduce_single_rank = True
+    for _ in range(steps):
         opt.zero_grad()
         out = rendering(o, d, t)
         loss, stats = training_loss(out['coarse_image'], out['fine_image'], target, out['regularization'], 1.0, 1.0,
@@ -78,3 +79,78 @@ def test_two_rank_fused_step_equals_single_process(tmp_path):
     for a, b, p0 in zip(r0['params'], ref, init):
         moved = (b - p0).abs().max().item()                     # ~3e-3 after three Adam steps of lr 1e-3
         assert (a - b).abs().max().item() <= 0.05 * moved + 1e-7, ((a - b).abs().max().item(), moved)
+
+
+def _worker_nan(rank, world, port, out_dir):
+    """Step 0 and 2 are clean, in step 1 the target of rank 1 holds a NaN (-> its loss, its image gradients and therefore
+    its parameter gradients are NaN, and its non-finite counter is 1 while rank 0's is 0)."""
+    _setup_paths()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sunerf_hip.dist import shard_range
+    from sunerf_hip.train import ClipAdam, training_loss
+    o, d, t, target = _batch()
+    b, e = shard_range(o.shape[0], rank, world)
+    o, d, t, target = (x[b:e].contiguous() for x in (o, d, t, target))
+    rendering = _module()
+    opt = ClipAdam(rendering.parameters(), lr=1e-3, max_norm=0.5)
+    log = []
+    for step in range(3):
+        tgt = target.clone()
+        if step == 1 and rank == 1:
+            tgt[3, 0] = float('nan')
+        opt.zero_grad()
+        out = rendering(o, d, t)
+        loss, stats = training_loss(out['coarse_image'], out['fine_image'], tgt, out['regularization'], 1.0, 1.0,
+                                    asinh_scaling=(1.0, 0.005), finite_check=[tgt])
+        loss.backward()
+        opt.step(skip_if_positive=stats[5:6])
+        log.append({'skipped': opt.skipped_last_step(), 'count': opt.nonfinite.item(), 'steps': opt.step_count,
+                    'params': [p.detach().cpu().clone() for p in rendering.parameters()]})
+    torch.save(log, os.path.join(out_dir, f'nan_rank{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_non_finite_on_one_rank_skips_the_step_on_every_rank(tmp_path):
+    """SURVEY.md 8e / sunerf.py:105-107: the non-finite counter rides at the tail of the all-reduced gradient bucket, so the
+    rank that did NOT see the NaN skips too -- replicas stay bit-identical and finite, and the step counter of the bias
+    correction does not advance on either."""
+    world, port = 2, 29547
+    mp.spawn(_worker_nan, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / 'nan_rank0.pt')
+    r1 = torch.load(tmp_path / 'nan_rank1.pt')
+    assert [x['skipped'] for x in r0] == [False, True, False] == [x['skipped'] for x in r1]
+    assert [x['steps'] for x in r0] == [1, 1, 2] == [x['steps'] for x in r1]
+    assert r0[1]['count'] == r1[1]['count'] and r0[1]['count'] >= 1          # the GLOBAL count, on both ranks
+    for s0, s1 in zip(r0, r1):
+        for a, b in zip(s0['params'], s1['params']):
+            assert torch.equal(a, b) and torch.isfinite(a).all()
+    for a, b in zip(r0[0]['params'], r0[1]['params']):
+        assert torch.equal(a, b)                                             # the skipped step changed nothing
+    assert any(not torch.equal(a, b) for a, b in zip(r0[1]['params'], r0[2]['params']))
+
+
+def _worker_rccl(rank, world, port, out_dir):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=rank, world_size=world)
+    o, d, t, target = _batch()
+    params, norm = _train(_module(), o, d, t, target, True, steps=2)
+    torch.save({'params': params, 'norm': norm}, os.path.join(out_dir, 'rccl.pt'))
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_runs_the_bucket_all_reduce(tmp_path):
+    """backend='nccl' IS RCCL on ROCm.  One GPU cannot host two RCCL ranks, so this is the world-size-1 case through the real
+    library (communicator set-up + the all-reduce call on the flat bucket inside ClipAdam.step): it must equal the
+    process-group-free step.  The N > 1 exchange itself is covered with gloo above and run by the driver on 8 GPUs."""
+    mp.spawn(_worker_rccl, args=(1, 29549, str(tmp_path)), nprocs=1, join=True)
+    got = torch.load(tmp_path / 'rccl.pt')
+    _setup_paths()
+    o, d, t, target = _batch()
+    ref, ref_norm = _train(_module(), o, d, t, target, False, steps=2)
+    assert torch.equal(got['norm'], ref_norm)
+    for a, b in zip(got['params'], ref):
+        assert torch.equal(a, b)

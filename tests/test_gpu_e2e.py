@@ -10,7 +10,7 @@ behind the inverse-CDF resampling, which amplifies coarse-weight noise (SURVEY.m
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import gate_units, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -31,8 +31,15 @@ def rel(a, b):
     return err / max(b.abs().max().item(), 1e-6)     # all-zero reference (e.g. no absorption anywhere): absolute
 
 
-@pytest.mark.parametrize('name,d_filter,n_c,n_f', [('g5_emission_e2e', 64, 32, 32), ('g5b_emission_d256', 256, 32, 64)])
+@pytest.mark.parametrize('name,d_filter,n_c,n_f', [('g5_emission_e2e', 64, 32, 32), ('g5b_emission_d256', 256, 32, 64),
+                                                  ('g11_trained', 64, 16, 16)])
 def test_forward_matches_reference(name, d_filter, n_c, n_f, precision):
+    """All 8 outputs of the module API against the reference's own.  coarse_image is held to the north-star gate per ray.
+    The fine pass sits behind the inverse-CDF resampling (sampling.py:128-169), which divides by CDF steps as small as 1e-5:
+    rounding differences of the coarse weights (1e-6 relative) move individual fine samples by up to 2e-4 in z, so END TO END
+    the fine outputs COULD leave the gate although each stage is inside it; measured they do not (0.002 ... 0.13 gate units
+    on g5 / g5b / g11), so they are held to the same 1e-4 per ray; the fine pass fed with the reference's
+    own sample positions is tests/test_gpu_precision.py::test_fine_pass_stagewise_with_reference_z_vals_combined."""
     g = load_golden(name)
     mod = _module(g, d_filter, n_c, n_f)
     out = mod(g['rays_o'].cuda(), g['rays_d'].cuda(), g['times'].cuda())
@@ -42,10 +49,21 @@ def test_forward_matches_reference(name, d_filter, n_c, n_f, precision):
         assert v.shape == g['out__' + k].shape, k
         assert torch.isfinite(v).all(), k
     assert torch.equal(out['z_vals_stratified'].cpu(), g['out__z_vals_stratified'])
-    assert rel(out['coarse_image'], g['out__coarse_image']) < 1e-4
-    assert (out['z_vals_hierarchical'].cpu() - g['out__z_vals_hierarchical']).abs().max().item() < 2e-4
+    units = {'coarse_image': gate_units(out['coarse_image'], g['out__coarse_image'])}
+    assert units['coarse_image'] <= 1.0
+    # inverse CDF: t = (u - cdf_lo) / denom with a denom as small as 1e-5 in an (almost) empty bin (sampling.py:164-166)
+    # multiplies the 6e-8 rounding of the cdf by up to 6e-3: samples in such bins -- which carry no weight -- move by up to
+    # that fraction of a coarse bin; everywhere else the positions agree to 2e-4 (13 ulp of z ~ 215)
+    dz = (out['z_vals_hierarchical'].cpu() - g['out__z_vals_hierarchical']).abs()
+    zc = g['out__z_vals_stratified']
+    assert dz.max().item() <= 1e-2 * (zc[:, 1:] - zc[:, :-1]).abs().max().item()
+    assert (dz > 2e-4).float().mean().item() <= 0.01
     for k in ('fine_image', 'image', 'height_map', 'absorption_map'):
-        assert rel(out[k], g['out__' + k]) < 2e-4, k
+        floor = (n_c + n_f) * 6e-8 if k == 'absorption_map' else 0.0      # sum of fp32 (1 - a): 2^-24 absolute per sample
+        units[k] = gate_units(out[k], g['out__' + k], floor)
+    print(name, precision, {k: round(v, 3) for k, v in units.items()})
+    for k in ('fine_image', 'image', 'height_map', 'absorption_map'):
+        assert units[k] <= 1.0, (k, units[k])
     # (golden rays have |d| != 1: samples far from the origin amplify the error of 1 - absorption, see test_gpu_stages)
     tol = 2e-4 if precision == 'exact' else 1e-3
     assert (out['regularization'].cpu() - g['out__regularization']).abs().max().item() \

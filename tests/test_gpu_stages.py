@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import sunerf_oracle as orc
-from conftest import load_golden, params_from_golden
+from conftest import gate_units, load_golden, params_from_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -62,11 +62,12 @@ def test_render_pass_vs_oracle(ops, d_filter, n_layers, S, precision):
                                   want_raw=True, want_epilogues=True)
     torch.cuda.synchronize()
     assert (out['raw'].cpu() - ref['raw']).abs().max().item() < 2e-5
-    assert rel_err(out['image'], ref['image']) < 1e-4
+    # per-ray outputs: the north-star bound per ray; (N, S) intermediates: relative to the row-independent maximum
+    assert gate_units(out['image'], ref['image']) <= 1.0
+    assert gate_units(out['height_map'], (ref['weights'] * dist_pts).sum(-1)) <= 1.0
+    assert gate_units(out['absorption_map'], (1 - ref['regularizing_quantity']).sum(-1), floor=S * 6e-8) <= 1.0
     assert rel_err(out['weights'], ref['weights']) < 1e-4
     assert rel_err(out['absorption'], ref['regularizing_quantity']) < 1e-4
-    assert rel_err(out['height_map'], (ref['weights'] * dist_pts).sum(-1)) < 1e-4
-    assert rel_err(out['absorption_map'], (1 - ref['regularizing_quantity']).sum(-1)) < 1e-4
     reg = torch.relu(dist_pts - 1.2) * (1 - ref['regularizing_quantity'])
     # these rays have |d| != 1, so the samples sit up to 40 radii from the origin and relu(|p| - 1.2) multiplies the error of
     # (1 - absorption) by up to 40: 1e-4 of the maximum needs the exact arithmetic; the fp8-correction mode (raw output

@@ -142,6 +142,30 @@ def test_clip_adam_skips_on_flag(train):
     flag = torch.tensor([2.0]).cuda()
     opt.step(skip_if_positive=flag)
     assert torch.equal(p.detach().cpu(), torch.ones(1000))
+    assert opt.skipped_last_step() and opt.step_count == 0          # a skipped step does not advance the bias correction
+    assert torch.equal(opt.exp_avg.cpu(), torch.zeros(1000))
     flag.zero_()
+    p.grad.fill_(1.0)
     opt.step(skip_if_positive=flag)
-    assert (p.detach() < 1.0).all()
+    assert not opt.skipped_last_step() and opt.step_count == 1
+    # first APPLIED step: m / (1 - beta1) = g, sqrt(v / (1 - beta2)) = |g|  ->  the update is lr (0.0744 with step = 2)
+    assert (p.detach().cpu() - 0.9).abs().max().item() < 1e-5
+
+
+def test_clip_adam_skips_on_non_finite_gradient(train):
+    """A NaN / Inf that only shows up in the gradients (e.g. an fp16 overflow in the backward pass) must not reach the
+    parameters: the total norm is not finite -> the update is skipped, with or without clipping."""
+    for max_norm in (0.5, None):
+        for bad in (float('nan'), float('inf')):
+            p = torch.nn.Parameter(torch.ones(3000).cuda())
+            opt = train.ClipAdam([p], lr=0.1, max_norm=max_norm)
+            p.grad.fill_(0.5)
+            p.grad[1234] = bad
+            opt.step()
+            assert opt.skipped_last_step() and opt.step_count == 0
+            assert torch.equal(p.detach().cpu(), torch.ones(3000))
+            assert torch.equal(opt.exp_avg.cpu(), torch.zeros(3000)) and torch.equal(opt.exp_avg_sq.cpu(), torch.zeros(3000))
+            opt.zero_grad()
+            p.grad.fill_(0.5)
+            opt.step()
+            assert not opt.skipped_last_step() and opt.step_count == 1 and (p.detach() < 1.0).all()
