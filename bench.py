@@ -6,15 +6,16 @@
 Workload (BASELINE.json metric: ray-samples/sec/GPU (fwd+bwd), 1024^2 image x 128 samples): a synthetic 1024 x 1024
 observer frame, 128 samples per ray, 8 x 256 sine MLP, fp32 parameters.  One step = one optimiser
 step of the hot path on this rank's next batch of ``--batch`` rays (default 32768 = 1/32 of the frame) that are
-resident in HBM before the timed region: fused forward render (with activation stash), loss of sunerf.py:110-120
+resident in HBM before the timed region: sample placement, fused forward render (with activation stash), loss of sunerf.py:110-120
 (asinh-scaled MSE + regularization mean), backward (integral, dgrad, wgrad), gradient all-reduce over the ranks
 (RCCL), clip_grad_norm_(0.5) and Adam.  Rays are sharded over ranks by image rows, every rank works on equally sized
 batches of its own rows (weak scaling); value = ray-samples of all ranks / max-over-ranks wall time.
 ``--mode fwd`` times the inference render of the whole frame instead (configs[1] of BASELINE.json).
 
 The JSON line carries
-  roofline     : algorithmic GEMM FLOPs of the dominant kernel (sunerf_emission_render_fwd) per launch / its average
-                 duration measured with HIP events on the launch stream, against the dense f16 MFMA peak
+  roofline     : algorithmic GEMM FLOPs of the dominant kernel (the fused render pass, sunerf_emission_render_fwd) per launch
+                 / its average duration between HIP events recorded around its launches in the timed region, on the launch
+                 stream, against the dense f16 MFMA peak; "step" inside it: the same for all kernels of a step together
   cpu_baseline : the CPU oracle (port of the reference's aten op sequence) timed on this host's cores on a bounded
                  sample of the same workload (rank 0, N = 1 only)
 """
@@ -167,16 +168,25 @@ def main():
     ap.add_argument('--batch', type=int, default=32768, help='rays per rank and optimiser step (train mode)')
     ap.add_argument('--mode', choices=['train', 'fwd'], default='train')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-half', action='store_true', help='skip the HALF-precision figure reported beside the headline')
+    ap.add_argument('--half', action='store_true', help='also time the opt-in HALF arithmetic (single fp16 operands: forward '
+                                                        'parity against an fp16-emulating oracle only; reported under "half_precision")')
     ap.add_argument('--no-two-pass', action='store_true', help='skip the reference-shaped two-pass figure (train mode)')
-    ap.add_argument('--dt', action='store_true', help='also time BASELINE config 5: density-temperature head, two-pass, '
-                                                      '256 samples per ray in the fine pass (reported under "dt_two_pass")')
+    ap.add_argument('--no-small-batch', action='store_true', help="skip the figure at the reference's own batch of 3072 rays")
+    ap.add_argument('--no-dt', action='store_true', help='skip BASELINE config 5: density-temperature head, two-pass, 128 + 256 '
+                                                         'samples per ray (reported under "dt_two_pass")')
     ap.add_argument('--d-filter', type=int, default=D_FILTER, help='MLP width (headline: 256; 512 = reference default)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` started directly: become the launcher.  A child process, started before anything here
+        # has touched a GPU (never an exec: see the GPU-box rules), one rank per GPU over RCCL; its output is relayed.
+        import subprocess
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', os.environ.get('MASTER_PORT', '29577'),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     globals()['D_FILTER'] = args.d_filter
-    precision = os.environ.get('SUNERF_FORWARD_PRECISION', 'fast').lower()
-    fast, half = precision == 'fast', precision == 'half'
-    FP8C = ('true' if fast else 'false') + (', true' if half else '')
+    precision = os.environ.get('SUNERF_FORWARD_PRECISION', 'auto').lower()
+    half = precision == 'half'
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -209,18 +219,49 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # HIP events around every launch of the dominant kernel (the fused render pass) inside the timed region, recorded on
+    # the stream the kernel is launched on (torch's current stream: ops._stream)
+    render_events, recording = [], {'on': False}
+    real_render = ops.emission_render_fwd
+
+    def timed_render(*a, **k):
+        if not recording['on']:
+            return real_render(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = real_render(*a, **k)
+        e1.record()
+        render_events.append((e0, e1))
+        return out
+    ops.emission_render_fwd = timed_render
+
+    def timed_loop(step, steps, warmup):
+        """``warmup`` untimed steps, then exactly ``steps`` steps between two barrier + synchronize pairs; max over ranks."""
+        for i in range(warmup):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = step(warmup + i)
+        barrier()
+        el = torch.tensor([time.perf_counter() - t0], device=dev)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        assert torch.isfinite(out).all()
+        return el.item()
+
     if args.mode == 'fwd':
-        # every rank renders a full frame seen from its own longitude
+        # every rank renders a full frame seen from its own longitude; a step = sample placement + fused render of the frame
         rays_o, rays_d = observer_rays(args.res, theta=-0.3 + 0.05 * rank, device=dev)
         n_rays = rays_o.shape[0]
         times = torch.zeros(n_rays, device=dev)
-        z_vals = ops.sample_z(ops.SAMPLER_STRATIFIED, rays_o, rays_d, t_vals, 1.3, 1.0)
         rays_per_step = n_rays
 
         def step(i):
+            z_vals = ops.sample_z(ops.SAMPLER_STRATIFIED, rays_o, rays_d, t_vals, 1.3, 1.0)
             return ops.emission_render_fwd(model.packed(), rays_o, rays_d, times, z_vals, reg_radius=1.2,
                                            want_epilogues=True)['image']
-        flops_per_sample, kernel_name = flops_fwd(D_FILTER), f'render_fwd_kernel<{D_FILTER}, false, {FP8C}>'
+        flops_step = flops_fwd(D_FILTER)
     else:
         # this rank's rows of the frame; batches of --batch rays cycle through them
         r0, r1 = shard_range(args.res, rank, world)
@@ -230,92 +271,100 @@ def main():
         rays_o, rays_d = rays_o[perm].contiguous(), rays_d[perm].contiguous()      # pre-shuffled ray pool
         times = torch.rand(n_local, generator=torch.Generator().manual_seed(0)).to(dev)
         target = torch.rand(n_local, 1, generator=torch.Generator().manual_seed(1)).to(dev)
-        z_all = ops.sample_z(ops.SAMPLER_STRATIFIED, rays_o, rays_d, t_vals, 1.3, 1.0)
         B = min(args.batch, n_local)
-        n_batches = n_local // B
         rays_per_step = B
         # sunerf.py:31 Adam(lr 1e-4) + run_emission.py:72 gradient_clip_val 0.5, on flat buffers; step() all-reduces the
-        # gradient bucket over the ranks (RCCL), then norm -> clip -> Adam in two kernels, no host synchronisation
+        # gradient bucket (+ the non-finite count at its tail) over the ranks (RCCL), then norm -> clip -> Adam in two
+        # kernels, no host synchronisation
         opt = ClipAdam(model.parameters(), lr=1e-4, max_norm=0.5)
 
-        def step(i):
-            b = (i % n_batches) * B
-            sl = slice(b, b + B)
-            opt.zero_grad()
-            out = emission_pass(model, rays_o[sl], rays_d[sl], times[sl], z_all[sl], 1.2, want_epilogues=True)
-            # single-pass workload: the one image plays both roles of sunerf.py:112-119 (0.5 * (mse + mse) = mse)
-            loss, stats = training_loss(out['image'], out['image'], target[sl], out['regularization'], 0.5, 1.0,
-                                        asinh_scaling=(1.0, 0.005), finite_check=[out['height_map'], out['absorption_map']])
-            loss.backward()
-            opt.step(skip_if_positive=stats[5:6])
-            return loss
-        flops_per_sample, kernel_name = flops_fwd(D_FILTER) + flops_bwd(D_FILTER), f'render_fwd_kernel<{D_FILTER}, true, {FP8C}> + dgrad + wgrad'
+        def make_step(batch):
+            n_batches = n_local // batch
 
+            def step(i):
+                b = (i % n_batches) * batch
+                sl = slice(b, b + batch)
+                opt.zero_grad()
+                # a-1 (sampling.py:68-91) is part of the step: sample placement for this batch
+                z = ops.sample_z(ops.SAMPLER_STRATIFIED, rays_o[sl], rays_d[sl], t_vals, 1.3, 1.0)
+                out = emission_pass(model, rays_o[sl], rays_d[sl], times[sl], z, 1.2, want_epilogues=True)
+                # single-pass workload: the one image plays both roles of sunerf.py:112-119 (0.5 * (mse + mse) = mse)
+                loss, stats = training_loss(out['image'], out['image'], target[sl], out['regularization'], 0.5, 1.0,
+                                            asinh_scaling=(1.0, 0.005), finite_check=[out['height_map'], out['absorption_map']])
+                loss.backward()
+                opt.step(skip_if_positive=stats[5:6])
+                return loss
+            return step
+        step = make_step(B)
+        flops_step = flops_fwd(D_FILTER) + flops_bwd(D_FILTER)
+
+    # ---- the headline: W warm-up steps, exactly K timed steps ----
     for i in range(args.warmup):
         step(i)
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    recording['on'] = True
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record()          # on the current stream == the stream the kernels are launched on
         out = step(args.warmup + i)
-        ev[i][1].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    step_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    recording['on'] = False
+    render_ms = sum(a.elapsed_time(b) for a, b in render_events) / max(1, len(render_events))
     assert torch.isfinite(out).all()
-
     el = torch.tensor([elapsed], device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
-    half_line = None
-    if precision == 'fast' and not args.no_half:
-        # beside the headline: the same step in the opt-in HALF arithmetic (single fp16 MFMA operands, fp32 accumulate --
-        # the "bf16 MLP weights on MFMA" class of BASELINE config 3).  Never the headline: it follows an fp16-emulating
-        # oracle to 1e-4, not the fp32 reference.
+    mode_used = ops.PRECISION_NAMES[model.packed().precision]       # what AUTO settled on (fast unless the probe objected)
+    probe_units = model.packed().last_probe
+
+    extras = {}
+    if args.mode == 'train' and not args.no_small_batch and n_local >= 3072:
+        # the reference's own batch (config/sunerfs_simple_star.yaml:8: 3072 rays per GPU): launch-bound regime
+        ss = 50
+        e = timed_loop(make_step(3072), ss, 5)
+        extras['small_batch'] = {'value': 3072 * args.samples * world * ss / e, 'unit': 'ray-samples/s', 'rays_per_step_per_gpu': 3072,
+                                 'ms_per_step': e / ss * 1e3, 'steps': ss,
+                                 'what': "the same step at the reference's own batch size (config/sunerfs_simple_star.yaml:8)"}
+    if args.half and not half:
+        # opt-in: the same step in the HALF arithmetic (single fp16 MFMA operands, fp32 accumulate -- the "bf16 MLP weights
+        # on MFMA" class of BASELINE config 3).  Never the headline: its forward follows an fp16-emulating oracle to 1e-4, not
+        # the fp32 reference.
         os.environ['SUNERF_FORWARD_PRECISION'] = 'half'
         model._packed = None
         hs = max(2, args.steps // 2)
-        for i in range(2):
-            step(i)
-        barrier()
-        th = time.perf_counter()
-        for i in range(hs):
-            step(2 + i)
-        barrier()
-        eh = torch.tensor([time.perf_counter() - th], device=dev)
-        if world > 1:
-            dist.all_reduce(eh, op=dist.ReduceOp.MAX)
+        e = timed_loop(step, hs, 2)
         os.environ['SUNERF_FORWARD_PRECISION'] = precision
         model._packed = None
-        half_line = {'value': rays_per_step * args.samples * world * hs / eh.item(), 'unit': 'ray-samples/s',
-                     'ms_per_step': eh.item() / hs * 1e3, 'steps': hs,
-                     'what': 'the same step with SUNERF_FORWARD_PRECISION=half: single fp16 MFMA operands, fp32 accumulate '
-                             '(arithmetic class of BASELINE config 3); parity gate: fp16-emulating oracle at 1e-4, NOT the '
-                             'fp32 reference -- reported beside the headline, never as it'}
-    two_pass = dt_two_pass = None
+        extras['half_precision'] = {'value': rays_per_step * args.samples * world * hs / e, 'unit': 'ray-samples/s',
+                                    'ms_per_step': e / hs * 1e3, 'steps': hs,
+                                    'what': 'the same step with SUNERF_FORWARD_PRECISION=half (opt-in): single fp16 MFMA operands, '
+                                            'fp32 accumulate; forward parity against an fp16-emulating oracle at 1e-4, NOT the fp32 '
+                                            'reference -- reported beside the headline, never as it'}
     if args.mode == 'train' and not args.no_two_pass:      # after the timed region of the headline metric
         del opt, model
         torch.cuda.empty_cache()
-        two_pass = two_pass_rate(dev, world, rays_o, rays_d, times, target, B, args.samples)
-        if args.dt:
+        extras['two_pass'] = two_pass_rate(dev, world, rays_o, rays_d, times, target, B, args.samples)
+        if not args.no_dt:
             torch.cuda.empty_cache()
-            dt_two_pass = two_pass_rate(dev, world, rays_o, rays_d, times, target, min(B, 8192), 256, density_temperature=True)
+            extras['dt_two_pass'] = two_pass_rate(dev, world, rays_o, rays_d, times, target, min(B, 8192), 256,
+                                                  density_temperature=True)
     samples_per_step = rays_per_step * args.samples * world
     value = samples_per_step * args.steps / elapsed
 
     if rank == 0:
-        achieved = rays_per_step * args.samples * flops_per_sample / (step_ms * 1e-3) / 1e12
+        fast = mode_used == 'fast'
+        FP8C = ('true' if fast else 'false') + (', true' if half else '')
+        kernel_name = f"render_fwd_kernel<{D_FILTER}, {'true' if args.mode == 'train' else 'false'}, {FP8C}>"
+        # dominant kernel = the fused render pass: algorithmic GEMM FLOPs of one launch / its average duration between the
+        # HIP events recorded around its launches in the timed region
+        achieved = rays_per_step * args.samples * flops_fwd(D_FILTER) / (render_ms * 1e-3) / 1e12
+        step_ms = elapsed / args.steps * 1e3
+        step_achieved = rays_per_step * args.samples * flops_step / (step_ms * 1e-3) / 1e12
         # matrix-pipe work of the forward per algorithmic flop: EXACT 3 fp16 products; FAST 1 fp16 product + two 64-deep
         # fp8 instructions per four 16-deep steps (measured 84 cycles each against 4 x 32: tools/probes/bench_mfma_mix.hip)
         fwd_factor = 1.0 if half else (1.0 + 2.0 * 84.0 / 128.0 if fast else 3.0)
-        if args.mode == 'fwd':
-            executed_factor = fwd_factor
-        else:
-            dgrad = flops_bwd(D_FILTER) - flops_fwd(D_FILTER)
-            executed_factor = (fwd_factor * flops_fwd(D_FILTER) + 2.0 * dgrad + flops_fwd(D_FILTER)) / flops_per_sample
-        traffic = None
+        traffic = traffic_source = None
         for tname in ('hbm_traffic.json', 'hbm_traffic_d512.json'):
             tpath = os.path.join(ROOT, 'profiles', tname)
             if not os.path.exists(tpath):
@@ -325,11 +374,14 @@ def main():
             measured_on = t.get(f'{args.mode}_config', {})
             here = {'rays': rays_per_step, 'samples': args.samples, 'd_filter': D_FILTER}
             if all(measured_on.get(k) == v for k, v in here.items()):
-                traffic = t.get(f'{args.mode}_bytes_per_step')
+                traffic = t.get(f'{args.mode}_kernel_bytes', t.get(f'{args.mode}_bytes_per_step'))
+                traffic_source = (f'profiles/{tname}: rocprofv3 PMC (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) of this '
+                                  'configuration, ' + ('the render kernel alone' if f'{args.mode}_kernel_bytes' in t else
+                                                       'whole step') + ' -- not measured in this run')
         what = 'fwd+bwd' if args.mode == 'train' else 'fwd'
         line = {
             'metric': f'ray-samples/sec ({what}, fused emission renderer)', 'value': value, 'unit': 'ray-samples/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': step_ms,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f16 MFMA operands, fp32 accumulate and parameters (opt-in HALF mode: the bf16-class arithmetic of BASELINE '
                      'config 3; follows an fp16-emulating oracle to 1e-4, NOT the fp32 reference)' if half else
@@ -339,26 +391,24 @@ def main():
             'data': 'synthetic',
             'config': {'workload': (f'emission render {what}, {args.res}x{args.res} frame x {args.samples} samples/ray, '
                                     f'{N_LAYERS}x{D_FILTER} sine MLP, '
-                                    + (f'{rays_per_step} rays per optimiser step and GPU (render+loss+backward+all-reduce+clip+Adam)'
-                                       if args.mode == 'train' else 'whole frame per step and GPU')),
-                       'rays_per_step_per_gpu': rays_per_step, 'samples_per_ray': args.samples, 'mode': args.mode},
+                                    + (f'{rays_per_step} rays per optimiser step and GPU (sample placement+render+loss+backward+'
+                                       'all-reduce+clip+Adam)' if args.mode == 'train' else 'whole frame per step and GPU (sample '
+                                       'placement + render)')),
+                       'rays_per_step_per_gpu': rays_per_step, 'samples_per_ray': args.samples, 'mode': args.mode,
+                       'forward_precision': f'{precision} -> {mode_used}' + (f' (probe: {probe_units:.3f} gate units)'
+                                                                             if probe_units is not None else '')},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F16_DENSE_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F16_DENSE_TFLOPS, 'traffic': traffic,
-                         'kernel': kernel_name, 'step_ms_hip_events': step_ms,
-                         'flops_per_sample': flops_per_sample,
+                         'frac': achieved / PEAK_F16_DENSE_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_source,
+                         'kernel': kernel_name, 'kernel_ms_hip_events': render_ms, 'launches_timed': len(render_events),
+                         'flops_per_sample': flops_fwd(D_FILTER),
                          'frac_of_f32_mfma_peak': achieved / PEAK_F32_MFMA_TFLOPS,
-                         # matrix-pipe time actually spent, in fp16-MFMA equivalents: forward see fwd_factor, the data
-                         # gradient 2 (hi + lo weights), the weight gradient 1
-                         'executed_frac': achieved * executed_factor / PEAK_F16_DENSE_TFLOPS,
-                         # average HBM rate of the step against the 8 TB/s peak (PMC traffic of this configuration)
-                         'hbm_frac': (traffic / (step_ms * 1e-3) / 8e12) if traffic else None},
+                         # matrix-pipe time actually spent by this kernel, in fp16-MFMA equivalents
+                         'executed_frac': achieved * fwd_factor / PEAK_F16_DENSE_TFLOPS,
+                         # the whole step (all kernels) on the same scale: algorithmic FLOPs of the step / ms_per_step
+                         'step': {'achieved': step_achieved, 'frac': step_achieved / PEAK_F16_DENSE_TFLOPS,
+                                  'flops_per_sample': flops_step}},
         }
-        if half_line is not None:
-            line['half_precision'] = half_line
-        if two_pass is not None:
-            line['two_pass'] = two_pass
-        if dt_two_pass is not None:
-            line['dt_two_pass'] = dt_two_pass
+        line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.res, args.samples, args.mode)
         print(json.dumps(line), flush=True)
