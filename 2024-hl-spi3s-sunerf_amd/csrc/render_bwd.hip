@@ -29,6 +29,7 @@ constexpr int IB_RAYS = IB_THREADS / 32;
 __global__ __launch_bounds__(IB_THREADS) void integral_bwd_kernel(
     const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ g_image, const float* __restrict__ g_reg,
+    const float* __restrict__ g_weights, const float* __restrict__ g_absorption,
     float g_reg_const, float reg_radius, int64_t n_rays, int S, float* __restrict__ g_raw,
     unsigned* __restrict__ g_absmax_bits) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [IB_RAYS][3][Sp]: emerging intensity, a, dist
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(IB_THREADS) void integral_bwd_kernel(
   const float gi = g_image[ray];
   // ---- sweep 1 (along the ray): emerging_i = I_i * T_i, T the exclusive product of (a + 1e-10) ----
   float carry_T = 1.f, carry_z = 0.f;
+  float sum_em = 0.f, dot_gw = 0.f;      // per-lane partial sums (only used with g_weights)
   const float z0 = z[0], z1 = z[1];
   for (int c = 0; c < n_chunks; ++c) {
     const int i = 32 * c + n;
@@ -67,11 +69,24 @@ __global__ __launch_bounds__(IB_THREADS) void integral_bwd_kernel(
     }
     float excl = __shfl_up(pr, 1, 32);
     if (n == 0) excl = 1.f;
-    em_s[i] = valid ? expf(rr[0]) * dist * (carry_T * excl) : 0.f;
+    const float em_i = valid ? expf(rr[0]) * dist * (carry_T * excl) : 0.f;
+    em_s[i] = em_i;
     a_s[i] = a;
     dist_s[i] = dist;
+    if (g_weights) {
+      sum_em += em_i;
+      dot_gw += valid ? g_weights[ray * S + i] * em_i : 0.f;
+    }
     carry_T *= __shfl(pr, 31, 32);
     carry_z = __shfl(zi, 31, 32);
+  }
+  // weights = em / (sum em + 1e-10) (emission.py:49-50):  sum_k gw_k d weights_k / d em_i = gw_i / D - dot / D^2
+  float inv_den = 0.f, dot_over_den2 = 0.f;
+  if (g_weights) {
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) { sum_em += __shfl_xor(sum_em, d, 32); dot_gw += __shfl_xor(dot_gw, d, 32); }
+    inv_den = 1.f / (sum_em + 1e-10f);
+    dot_over_den2 = dot_gw * inv_den * inv_den;
   }
   // ---- sweep 2 (against the ray): suffix_i = sum_{k > i} emerging_k ----
   float local_max = 0.f, carry_suffix = 0.f;
@@ -79,20 +94,24 @@ __global__ __launch_bounds__(IB_THREADS) void integral_bwd_kernel(
     const int i = 32 * c + n;
     const bool valid = i < S;
     const float em = em_s[i];
-    float incl = em;                                   // inclusive suffix sum within the chunk
+    // gradient arriving at em_i: the image's (gi) and, when the caller differentiates the weights output too, theirs
+    const float ge = g_weights ? gi + (valid ? g_weights[ray * S + i] : 0.f) * inv_den - dot_over_den2 : gi;
+    const float wv = g_weights ? ge * em : em;         // (without g_weights: the sums of em itself, scaled by gi afterwards)
+    float incl = wv;                                   // inclusive suffix sum within the chunk
 #pragma unroll
     for (int d = 1; d < 32; d <<= 1) {
       const float o = __shfl_down(incl, d, 32);
       if (n + d < 32) incl += o;
     }
-    const float suffix = carry_suffix + (incl - em);
+    const float suffix = carry_suffix + (incl - wv);
     carry_suffix += __shfl(incl, 0, 32);
     if (valid && ray_ok) {
       const float a = a_s[i], dist = dist_s[i];
       const float r1 = r[2 * i + 1];
       // image = sum_i em_i :  d/d r0_i = em_i ;  d/d a_i = suffix_i / (a_i + 1e-10)
-      const float g0 = gi * em;
-      float ga = gi * suffix / (a + 1e-10f);
+      const float g0 = g_weights ? wv : gi * em;
+      float ga = (g_weights ? suffix : gi * suffix) / (a + 1e-10f);
+      if (g_absorption) ga += g_absorption[ray * S + i];        // the 'regularizing_quantity' output is a itself
       // regularization_i = relu(|p_i| - R) (1 - a_i)   (base_tracing.py:43-44, D2 resolved)
       const float gr = g_reg ? g_reg[ray * S + i] : g_reg_const;
       if (gr != 0.f) {
@@ -112,6 +131,60 @@ __global__ __launch_bounds__(IB_THREADS) void integral_bwd_kernel(
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, d));
   if ((tid & 63) == 0 && local_max > 0.f && local_max < INFINITY) atomicMax(g_absmax_bits, __float_as_uint(local_max));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// integral forward on a GIVEN raw tensor: EmissionRadiativeTransfer.raw2outputs (emission.py:14-54) as a stand-alone entry
+// point (the render kernel has the same arithmetic fused behind its MLP).  32 lanes per ray, chunk-wise product scan.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(IB_THREADS) void integral_fwd_kernel(
+    const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ rays_d, int64_t n_rays, int S,
+    float* __restrict__ image, float* __restrict__ weights, float* __restrict__ absorption) {
+  const int tid = threadIdx.x, n = tid & 31, sub = tid >> 5;
+  const int64_t ray = (int64_t)blockIdx.x * IB_RAYS + sub;
+  if (ray >= n_rays) return;                       // (a whole 32-lane group leaves: the shuffles below are 32 wide)
+  const int n_chunks = (S + 31) >> 5;
+  const float dx = rays_d[ray * 3 + 0], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+  const float dnorm = sqrtf((dx * dx + dy * dy) + dz * dz);
+  const float* z = z_vals + ray * S;
+  const float* r = raw + ray * S * 2;
+  float carry_T = 1.f, carry_z = 0.f, sum_em = 0.f;
+  const float z0 = z[0], z1 = z[1];
+  for (int c = 0; c < n_chunks; ++c) {
+    const int i = 32 * c + n;
+    const bool valid = i < S;
+    const float zi = z[valid ? i : S - 1];
+    float zprev = __shfl_up(zi, 1, 32);
+    if (n == 0) zprev = carry_z;
+    const float dist = ((i == 0) ? (z1 - z0) : (zi - zprev)) * dnorm;      // emission.py:19-24: first distance duplicated
+    const f32x2 rr = *(const f32x2*)(r + 2 * (valid ? i : S - 1));
+    const float a = expf(-fmaxf(rr[1], 0.f) * dist);
+    float pr = valid ? (a + 1e-10f) : 1.f;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+      const float o = __shfl_up(pr, d, 32);
+      if (n >= d) pr *= o;
+    }
+    float excl = __shfl_up(pr, 1, 32);
+    if (n == 0) excl = 1.f;
+    const float em = valid ? expf(rr[0]) * dist * (carry_T * excl) : 0.f;
+    float s = em;
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) s += __shfl_xor(s, d, 32);
+    sum_em += s;
+    if (valid) {
+      weights[ray * S + i] = em;                   // un-normalised; finalised below by the same lane
+      absorption[ray * S + i] = a;
+    }
+    carry_T *= __shfl(pr, 31, 32);
+    carry_z = __shfl(zi, 31, 32);
+  }
+  const float denom = sum_em + 1e-10f;
+  for (int c = 0; c < n_chunks; ++c) {
+    const int i = 32 * c + n;
+    if (i < S) weights[ray * S + i] = weights[ray * S + i] / denom;
+  }
+  if (n == 0) image[ray] = sum_em;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -516,8 +589,22 @@ extern "C" size_t sunerf_dz_stash_bytes(int64_t n_rays, int n_samples, int d_fil
   return (size_t)chunks * (size_t)(n_linear - 1) * (d_filter / 16) * 1024;
 }
 
+extern "C" int sunerf_emission_integral_fwd(const float* raw, const float* z_vals, const float* rays_d, int64_t n_rays,
+                                            int n_samples, float* image, float* weights, float* absorption, void* stream) {
+  if (n_rays < 0 || n_samples < 2) return SUNERF_E_BADARG;
+  if (n_rays == 0) return 0;
+  if (!raw || !z_vals || !rays_d || !image || !weights || !absorption) return SUNERF_E_BADARG;
+  const int64_t blocks = (n_rays + IB_RAYS - 1) / IB_RAYS;
+  SUNERF_CLEAR_ERROR();
+  hipLaunchKernelGGL(integral_fwd_kernel, dim3((unsigned)blocks), dim3(IB_THREADS), 0, (hipStream_t)stream, raw, z_vals, rays_d,
+                     n_rays, n_samples, image, weights, absorption);
+  SUNERF_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int sunerf_emission_integral_bwd(const float* raw, const float* z_vals, const float* rays_o, const float* rays_d,
-                                            const float* g_image, const float* g_reg, float g_reg_const, float reg_radius,
+                                            const float* g_image, const float* g_reg, const float* g_weights,
+                                            const float* g_absorption, float g_reg_const, float reg_radius,
                                             int64_t n_rays, int n_samples, float* g_raw, void* g_absmax, void* stream) {
   if (n_rays < 0 || n_samples < 2 || !g_absmax) return SUNERF_E_BADARG;
   if (n_rays > 0 && (!raw || !z_vals || !rays_o || !rays_d || !g_image || !g_raw)) return SUNERF_E_BADARG;
@@ -533,7 +620,8 @@ extern "C" int sunerf_emission_integral_bwd(const float* raw, const float* z_val
   const int64_t blocks = (n_rays + IB_RAYS - 1) / IB_RAYS;
   SUNERF_CLEAR_ERROR();
   hipLaunchKernelGGL(integral_bwd_kernel, dim3((unsigned)blocks), dim3(IB_THREADS), lds, (hipStream_t)stream, raw, z_vals,
-                     rays_o, rays_d, g_image, g_reg, g_reg_const, reg_radius, n_rays, n_samples, g_raw, (unsigned*)g_absmax);
+                     rays_o, rays_d, g_image, g_reg, g_weights, g_absorption, g_reg_const, reg_radius, n_rays, n_samples, g_raw,
+                     (unsigned*)g_absmax);
   SUNERF_CHECK_LAUNCH();
   return 0;
 }

@@ -3,7 +3,7 @@ import torch
 
 from sunerf.model.model import NeRF_DT
 from sunerf.rendering.base_tracing import SuNeRFRendering
-from sunerf.rendering.functional import dt_pass
+from sunerf.rendering.functional import dt_pass, dt_raw2outputs
 from sunerf_hip.genx import read_aia_temp_resp
 
 
@@ -44,5 +44,9 @@ class DensityTemperatureRadiativeTransfer(SuNeRFRendering):
                 'fine_image': fine['image'], 'image': fine['image'], 'height_map': fine['height_map'],
                 'absorption_map': fine['absorption_map'], 'regularization': fine['regularization']}
 
-    def raw2outputs(self, **kwargs):
-        raise NotImplementedError('raw2outputs is fused into sunerf_dt_integral_fwd; call forward()')
+    def raw2outputs(self, inferences, log_abs, vol_c, z_vals, rays_d, wavelengths, **kwargs):
+        """density_temperature.py:192-271 on the state ``NeRF_DT.forward`` returns (``inferences`` (N, S, 2) with the base
+        offsets added, the ``log_absortpion`` ParameterDict, ``volumetric_constant``): ``{'image' (N,W), 'weights',
+        'regularizing_quantity'}``; differentiable through ``image`` (sunerf_dt_integral_fwd / _bwd)."""
+        return dt_raw2outputs((self.response_logte, self.response_table), self.pixel_intensity_factor, inferences, log_abs,
+                              vol_c, z_vals, rays_d, wavelengths)

@@ -2,7 +2,7 @@
 import torch
 
 from sunerf.rendering.base_tracing import SuNeRFRendering
-from sunerf.rendering.functional import emission_pass
+from sunerf.rendering.functional import emission_pass, emission_raw2outputs
 
 
 class EmissionRadiativeTransfer(SuNeRFRendering):
@@ -26,5 +26,7 @@ class EmissionRadiativeTransfer(SuNeRFRendering):
                 'absorption_map': fine['absorption_map'], 'regularization': fine['regularization']}
 
     def raw2outputs(self, raw: torch.Tensor, z_vals: torch.Tensor, rays_d: torch.Tensor, **kwargs):
-        raise NotImplementedError('raw2outputs is fused into the render kernel (sunerf_emission_render_fwd); '
-                                  'call forward()')
+        """emission.py:14-54 on a given ``raw`` (N, S, 2): ``{'image' (N,1), 'weights' (N,S), 'regularizing_quantity' (N,S)}``,
+        differentiable w.r.t. ``raw`` (sunerf_emission_integral_fwd / _bwd).  ``forward`` does not come through here: it
+        runs the same arithmetic fused behind the MLP (sunerf_emission_render_fwd)."""
+        return emission_raw2outputs(raw, z_vals, rays_d)

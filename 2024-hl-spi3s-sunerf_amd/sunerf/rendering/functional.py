@@ -103,6 +103,64 @@ def emission_pass(model, rays_o, rays_d, times, z_vals, reg_radius, want_epilogu
                                    want_epilogues=want_epilogues)
 
 
+class _EmissionIntegral(torch.autograd.Function):
+    """``EmissionRadiativeTransfer.raw2outputs`` (emission.py:14-54) on a given raw tensor: differentiable w.r.t. ``raw`` through
+    all three outputs (image, weights, regularizing_quantity), like the reference's autograd graph."""
+
+    @staticmethod
+    def forward(ctx, raw, z_vals, rays_d):
+        image, weights, absorption = ops.emission_integral_fwd(raw.detach(), z_vals, rays_d)
+        ctx.save_for_backward(raw.detach(), z_vals, rays_d)
+        ctx.set_materialize_grads(False)
+        return image, weights, absorption
+
+    @staticmethod
+    def backward(ctx, g_image, g_weights, g_absorption):
+        raw, z_vals, rays_d = ctx.saved_tensors
+        if g_image is None and g_weights is None and g_absorption is None:
+            return None, None, None
+        return ops.emission_integral_bwd(raw, z_vals, rays_d, g_image, g_weights, g_absorption), None, None
+
+
+def emission_raw2outputs(raw, z_vals, rays_d):
+    image, weights, absorption = _EmissionIntegral.apply(raw, z_vals, rays_d)
+    return {'image': image, 'weights': weights, 'regularizing_quantity': absorption}
+
+
+class _DtIntegral(torch.autograd.Function):
+    """``DensityTemperatureRadiativeTransfer.raw2outputs`` (density_temperature.py:192-271) on given inferences (base offsets
+    already added, as ``NeRF_DT.forward`` returns them).  Differentiable through ``image`` w.r.t. the inferences, the seven
+    absorption scalars and the volumetric constant (what the loss of sunerf.py:187-195 needs)."""
+
+    @staticmethod
+    def forward(ctx, tables, pixel_factor, inferences, z_vals, rays_d, wavelengths, vol_c, *la):
+        la_vec = torch.stack([p.detach() for p in la])
+        zeros = torch.zeros_like(rays_d)
+        out = ops.dt_integral_fwd(inferences.detach(), z_vals, zeros, rays_d, wavelengths, tables[0], tables[1], la_vec, vol_c, 0.0, 0.0,
+                                  pixel_factor, 0.0)
+        ctx.tables, ctx.pixel_factor = tables, pixel_factor
+        ctx.save_for_backward(inferences.detach(), z_vals, rays_d, wavelengths, la_vec, vol_c.detach())
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(out['weights'], out['reg_q'])
+        return out['image'], out['weights'], out['reg_q']
+
+    @staticmethod
+    def backward(ctx, g_image, g_weights, g_q):
+        inferences, z_vals, rays_d, wavelengths, la_vec, vol_c = ctx.saved_tensors
+        if g_image is None:
+            return (None,) * (8 + la_vec.shape[0])
+        g_raw, g_la, g_vc, _ = ops.dt_integral_bwd(inferences, z_vals, torch.zeros_like(rays_d), rays_d, wavelengths, ctx.tables[0],
+                                                   ctx.tables[1], la_vec, vol_c, 0.0, 0.0, ctx.pixel_factor, 0.0,
+                                                   g_image.contiguous(), None)
+        return (None, None, g_raw, None, None, None, g_vc.reshape(())) + tuple(g_la[i] for i in range(g_la.shape[0]))
+
+
+def dt_raw2outputs(tables, pixel_factor, inferences, log_abs, vol_c, z_vals, rays_d, wavelengths):
+    la = [log_abs[str(w)] for w in ops.AIA_WAVELENGTHS]
+    image, weights, reg_q = _DtIntegral.apply(tables, pixel_factor, inferences, z_vals, rays_d, wavelengths, vol_c, *la)
+    return {'image': image, 'weights': weights, 'regularizing_quantity': reg_q}
+
+
 class _DtPass(torch.autograd.Function):
     """One fused density/temperature pass: render kernel (MLP) -> DT integral kernel.  Differentiable outputs: ``image``
     (N,W) and ``regularization``; gradients for the MLP parameters, the 7 ``log_absortpion`` scalars and

@@ -38,7 +38,9 @@ _SIGNATURES = {
                                           c_void, c_void]),
     'sunerf_dz_stash_bytes': (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     'sunerf_wgrad_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
-    'sunerf_emission_integral_bwd': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_float,
+    'sunerf_emission_integral_fwd': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, c_f32p,
+                                                     c_void]),
+    'sunerf_emission_integral_bwd': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_float,
                                                      ctypes.c_float, ctypes.c_int64, ctypes.c_int, c_f32p, c_void, c_void]),
     'sunerf_mlp_dgrad': (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_f32p, c_void, c_void, c_void,
                                          ctypes.c_int64, ctypes.c_int, c_void]),

@@ -287,8 +287,36 @@ def emission_render_bwd(packed: PackedMLP, rays_o, rays_d, z_vals, raw, stash, g
     absmax = torch.empty(1, dtype=torch.int32, device=dev)
     stream = _stream(dev)
     _l.call(dev, 'sunerf_emission_integral_bwd', _ptr(raw), _ptr(z_vals), _ptr(rays_o), _ptr(rays_d), _ptr(g_image),
-            _ptr(g_reg), float(g_reg_const), float(reg_radius), n, s, _ptr(g_raw), _ptr(absmax), stream)
+            _ptr(g_reg), None, None, float(g_reg_const), float(reg_radius), n, s, _ptr(g_raw), _ptr(absmax), stream)
     mlp_backward(packed, g_raw, absmax, stash, grad_weights, grad_biases, accumulate)
+    return g_raw
+
+
+def emission_integral_fwd(raw, z_vals, rays_d):
+    """EmissionRadiativeTransfer.raw2outputs (emission.py:14-54) on a given raw tensor -> (image (N,1), weights, absorption)."""
+    n, s = z_vals.shape
+    dev = z_vals.device
+    raw = _dev(raw, 'raw', (n, s, 2)); z_vals = _dev(z_vals, 'z_vals', (n, s)); rays_d = _dev(rays_d, 'rays_d', (n, 3))
+    f32 = dict(dtype=torch.float32, device=dev)
+    image, weights, absorption = torch.empty(n, 1, **f32), torch.empty(n, s, **f32), torch.empty(n, s, **f32)
+    _l.call(dev, 'sunerf_emission_integral_fwd', _ptr(raw), _ptr(z_vals), _ptr(rays_d), n, s, _ptr(image), _ptr(weights),
+            _ptr(absorption), _stream(dev))
+    return image, weights, absorption
+
+
+def emission_integral_bwd(raw, z_vals, rays_d, g_image=None, g_weights=None, g_absorption=None):
+    """d / d raw of :func:`emission_integral_fwd` for gradients w.r.t. any of its three outputs -> g_raw (N,S,2)."""
+    n, s = z_vals.shape
+    dev = z_vals.device
+    raw = _dev(raw, 'raw', (n, s, 2)); z_vals = _dev(z_vals, 'z_vals', (n, s)); rays_d = _dev(rays_d, 'rays_d', (n, 3))
+    g_image = torch.zeros(n, dtype=torch.float32, device=dev) if g_image is None else _dev(g_image.reshape(-1), 'g_image', (n,))
+    g_weights = None if g_weights is None else _dev(g_weights, 'g_weights', (n, s))
+    g_absorption = None if g_absorption is None else _dev(g_absorption, 'g_absorption', (n, s))
+    g_raw = torch.empty(n, s, 2, dtype=torch.float32, device=dev)
+    absmax = torch.empty(1, dtype=torch.int32, device=dev)
+    # (rays_o only enters through the regularization term, which is not an output of raw2outputs: g_reg = 0)
+    _l.call(dev, 'sunerf_emission_integral_bwd', _ptr(raw), _ptr(z_vals), _ptr(rays_d), _ptr(rays_d), _ptr(g_image), None,
+            _ptr(g_weights), _ptr(g_absorption), 0.0, 0.0, n, s, _ptr(g_raw), _ptr(absmax), _stream(dev))
     return g_raw
 
 

@@ -141,9 +141,19 @@ int sunerf_pack_mlp_t(const float* const* weights_host, int n_linear, int d_filt
 size_t sunerf_dz_stash_bytes(int64_t n_rays, int n_samples, int d_filter, int n_linear);
 size_t sunerf_wgrad_workspace_bytes(int d_filter, int n_linear, int split);
 
+/* EmissionRadiativeTransfer.raw2outputs (sunerf/rendering/emission.py:14-54, cumprod_exclusive base_tracing.py:135-156) on a
+ * GIVEN raw tensor -- the subclass hook SuNeRFRendering._render calls (base_tracing.py:128): raw (N,S,2), z_vals (N,S),
+ * rays_d (N,3) -> image (N), weights (N,S), absorption (N,S) = the 'regularizing_quantity'.  (Inside
+ * sunerf_emission_render_fwd the same arithmetic is fused behind the MLP.) */
+int sunerf_emission_integral_fwd(const float* raw, const float* z_vals, const float* rays_d, int64_t n_rays, int n_samples,
+                                 float* image, float* weights, float* absorption, void* stream);
+
+/* g_weights / g_absorption: optional (N,S) gradients w.r.t. the 'weights' and 'regularizing_quantity' outputs of
+ * raw2outputs (NULL on the training path, whose loss only reads image and regularization) */
 int sunerf_emission_integral_bwd(const float* raw, const float* z_vals, const float* rays_o, const float* rays_d,
-                                 const float* g_image, const float* g_reg, float g_reg_const, float reg_radius,
-                                 int64_t n_rays, int n_samples, float* g_raw, void* g_absmax, void* stream);
+                                 const float* g_image, const float* g_reg, const float* g_weights, const float* g_absorption,
+                                 float g_reg_const, float reg_radius, int64_t n_rays, int n_samples, float* g_raw,
+                                 void* g_absmax, void* stream);
 
 int sunerf_mlp_dgrad(const void* packedT, int d_filter, int n_linear, const float* g_raw, const void* g_absmax,
                      const void* act_stash, void* dz_stash, int64_t n_rays, int n_samples, void* stream);
