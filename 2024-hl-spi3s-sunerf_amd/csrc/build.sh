@@ -2,8 +2,8 @@
 # Builds libsunerf_hip.so (gfx950) in-tree.  Usage: ./build.sh [extra hipcc flags]
 set -e
 cd "$(dirname "$0")"
-OUT=../libsunerf_hip.so
-OBJ=../build_obj
+OUT=${SUNERF_BUILD_OUT:-../libsunerf_hip.so}     # variants for A/B runs: SUNERF_BUILD_OUT=... SUNERF_BUILD_OBJ=... ./build.sh -DFLAG
+OBJ=${SUNERF_BUILD_OBJ:-../build_obj}
 mkdir -p "$OBJ"
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result"
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in architectural VGPRs.  The render / dgrad kernels keep their activation

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Per-kernel time of the training step (rocprofv3 --kernel-trace --stats); usage on the GPU box: tools/kstats.sh TAG [bench flags]
+R=/root/repo
+TAG=$1; shift
+OUT=$R/gpurun_out/ks_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --no-cpu-baseline --no-two-pass --no-small-batch --steps 6 --warmup 2 "$@" > $OUT/run.log 2>&1
+f=$(find $OUT -name '*kernel_stats.csv' | head -1)
+python3 - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows[:4]:
+    print(f"{r['Name'][:70]:70s} calls {r['Calls']:>5s} avg_us {float(r['AverageNs'])/1e3:10.1f} pct {r['Percentage']}")
+PY
+cp "$f" $R/gpurun_out/ks_$TAG.csv
