@@ -43,15 +43,19 @@ class NeRF(nn.Module):
     def __init__(self, d_input: int = 4, d_output: int = 2, n_layers: int = 8, d_filter: int = 512,
                  skip: Tuple[int] = (), encoding='positional'):
         super().__init__()
-        if encoding != 'positional':
-            raise ValueError("only encoding='positional' is implemented by the fused kernel")
-        if d_filter not in ops.SUPPORTED_D_FILTER:
-            raise ValueError(f'd_filter={d_filter} is not in the compiled set {ops.SUPPORTED_D_FILTER}')
+        if not 1 <= d_filter <= ops.SUPPORTED_D_FILTER[-1]:
+            raise ValueError(f'd_filter={d_filter}: the fused kernels cover widths 1..{ops.SUPPORTED_D_FILTER[-1]} (compiled for '
+                             f'{ops.SUPPORTED_D_FILTER}; other widths run zero-padded to the next of these, which is exact)')
+        if d_input != 4:
+            raise ValueError('the fused kernels take (x, y, z, t) query points: d_input = 4 (emission.py:11, the only value used)')
         self.d_input = d_input
         self.skip = skip
         self.act = Sine()
-        enc = PositionalEncoding(d_input=d_input, n_freqs=10)
-        self.in_layer = nn.Sequential(enc, nn.Linear(enc.d_output, d_filter))
+        if encoding == 'positional':      # model.py:28-33
+            enc = PositionalEncoding(d_input=d_input, n_freqs=10)
+            self.in_layer = nn.Sequential(enc, nn.Linear(enc.d_output, d_filter))
+        else:                             # anything else: no encoding, the first layer reads the raw coordinates
+            self.in_layer = nn.Linear(d_input, d_filter)
         self.layers = nn.ModuleList([nn.Linear(d_filter, d_filter) for _ in range(n_layers - 1)])
         self.out_layer = nn.Linear(d_filter, d_output)
         self._packed = None
@@ -59,7 +63,8 @@ class NeRF(nn.Module):
 
     # -- parameter views in evaluation order -----------------------------------------------------------------
     def linears(self):
-        return [self.in_layer[1]] + list(self.layers) + [self.out_layer]
+        first = self.in_layer[1] if isinstance(self.in_layer, nn.Sequential) else self.in_layer
+        return [first] + list(self.layers) + [self.out_layer]
 
     def packed(self) -> 'ops.PackedMLP':
         """Packed image of the current parameters; re-packed when any parameter was modified in place

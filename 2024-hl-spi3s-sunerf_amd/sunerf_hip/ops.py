@@ -74,7 +74,18 @@ class PackedMLP:
 
     def __init__(self, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], precision: Optional[int] = None):
         self.n_linear = len(weights)
-        self.d_filter = int(weights[0].shape[0])
+        # Any width up to 512 and both input forms of NeRF (model.py:28-33) run on the compiled kernels by ZERO PADDING, which is
+        # exact: a padded hidden unit has zero weights and bias, sin(0) = 0, and zero outgoing weights; a first layer without
+        # positional encoding, Linear(4, d), is the 84-input layer with its weights in the four raw-coordinate columns (reference
+        # columns 0..3 of the encoder output, model.py:127-132) and zeros under the 80 sin / cos features.
+        self.d_model = int(weights[0].shape[0])
+        self.d_in = int(weights[0].shape[1])
+        if self.d_model < 1 or self.d_model > SUPPORTED_D_FILTER[-1]:
+            raise ValueError(f'd_filter={self.d_model} is outside 1..{SUPPORTED_D_FILTER[-1]}')
+        if self.d_in not in (4, 84):
+            raise ValueError('the first layer takes the 84 positional-encoding features or the 4 raw coordinates')
+        self.d_filter = next(d for d in SUPPORTED_D_FILTER if d >= self.d_model)
+        self.padded = self.d_filter != self.d_model or self.d_in != 84
         precision = default_precision(self.d_filter) if precision is None else int(precision)
         self.auto = precision == PRECISION_AUTO
         self.precision = PRECISION_FAST if self.auto else precision          # the kernel mode of `buffer`
@@ -82,10 +93,6 @@ class PackedMLP:
         self.last_probe = None            # gate units measured by the last probe (AUTO only)
         self._versions_since_probe = 0
         self.d_out = int(weights[-1].shape[0])
-        if self.d_filter not in SUPPORTED_D_FILTER:
-            raise ValueError(f'd_filter={self.d_filter} is not in the compiled set {SUPPORTED_D_FILTER}')
-        if int(weights[0].shape[1]) != 84:
-            raise ValueError("only encoding='positional' (84 input features) is supported by the fused kernel")
         lib = _l.load()
         nbytes = lib.sunerf_packed_mlp_bytes(self.d_filter, self.n_linear)
         if nbytes == 0:
@@ -94,11 +101,34 @@ class PackedMLP:
         self.buffer = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self.buffer_t = None        # transposed image for the backward pass, packed on demand
         self._t_valid = False
+        self._pad_w = self._pad_b = None
         self.repack(weights, biases)
 
+    def kernel_shapes(self):
+        """[(weight shape, bias shape)] of the (padded) network the kernels see."""
+        D = self.d_filter
+        return [((self.d_out if i == self.n_linear - 1 else D, 84 if i == 0 else D), (self.d_out if i == self.n_linear - 1 else D,))
+                for i in range(self.n_linear)]
+
+    def _padded(self, weights, biases):
+        """Copies the model's parameters into zero-initialised tensors of the kernel's shapes (device copies only)."""
+        if self._pad_w is None:
+            f32 = dict(dtype=torch.float32, device=self.device)
+            self._pad_w = [torch.zeros(ws, **f32) for ws, _ in self.kernel_shapes()]
+            self._pad_b = [torch.zeros(bs, **f32) for _, bs in self.kernel_shapes()]
+        for W, b, pw, pb in zip(weights, biases, self._pad_w, self._pad_b):
+            pw[:W.shape[0], :W.shape[1]].copy_(W.detach())
+            pb[:b.shape[0]].copy_(b.detach())
+        return self._pad_w, self._pad_b
+
     def repack(self, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]):
-        lib = _l.load()
         assert len(weights) == self.n_linear and len(biases) == self.n_linear
+        if self.padded:
+            for i, (w, b) in enumerate(zip(weights, biases)):
+                d_in = self.d_in if i == 0 else self.d_model
+                d_o = self.d_out if i == self.n_linear - 1 else self.d_model
+                _dev(w.detach(), f'weight[{i}]', (d_o, d_in)); _dev(b.detach(), f'bias[{i}]', (d_o,))
+            weights, biases = self._padded(weights, biases)
         ws, bs = [], []
         for i, (w, b) in enumerate(zip(weights, biases)):
             d_in = 84 if i == 0 else self.d_filter
@@ -334,6 +364,22 @@ def mlp_backward(packed: PackedMLP, g_raw, absmax, stash, grad_weights: Sequence
             _ptr(dz), n, s, stream)
     split = wgrad_split(nl, torch.cuda.get_device_properties(dev).multi_processor_count, D)
     ws = torch.empty(lib.sunerf_wgrad_workspace_bytes(packed.d_filter, nl, split), dtype=torch.uint8, device=dev)
+    out_w, out_b = list(grad_weights), list(grad_biases)
+    if packed.padded:
+        # zero-padded model (PackedMLP.__init__): the kernels produce gradients of the padded shapes; the model's are their
+        # leading blocks (the padding's own gradients are discarded: those weights are not parameters)
+        for i, (gw, gb) in enumerate(zip(out_w, out_b)):
+            d_in = packed.d_in if i == 0 else packed.d_model
+            d_o = packed.d_out if i == nl - 1 else packed.d_model
+            if gw.shape != (d_o, d_in) or gb.shape != (d_o,) or gw.dtype != torch.float32:
+                raise ValueError(f'grad buffer {i} has the wrong shape / layout')
+        if getattr(packed, '_pad_gw', None) is None:
+            f32 = dict(dtype=torch.float32, device=dev)
+            packed._pad_gw = [torch.empty(ws, **f32) for ws, _ in packed.kernel_shapes()]
+            packed._pad_gb = [torch.empty(bs, **f32) for _, bs in packed.kernel_shapes()]
+        grad_weights, grad_biases, kernel_accumulate = packed._pad_gw, packed._pad_gb, False
+    else:
+        kernel_accumulate = accumulate
     for i, (gw, gb) in enumerate(zip(grad_weights, grad_biases)):
         d_in = 84 if i == 0 else D
         d_o = packed.d_out if i == nl - 1 else D
@@ -341,8 +387,16 @@ def mlp_backward(packed: PackedMLP, g_raw, absmax, stash, grad_weights: Sequence
             raise ValueError(f'grad buffer {i} has the wrong shape / layout')
     GW = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grad_weights])
     GB = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grad_biases])
-    _l.call(dev, 'sunerf_mlp_wgrad', D, nl, packed.d_out, _ptr(stash), _ptr(dz), _ptr(g_raw), _ptr(absmax), n, s,
-            _ptr(ws), split, GW, GB, int(accumulate), stream)
+    _l.call(dev, 'sunerf_mlp_wgrad', D, nl, packed.d_out, _ptr(stash), _ptr(dz), _ptr(g_raw), _ptr(absmax), n, s, _ptr(ws),
+            split, GW, GB, int(kernel_accumulate), stream)
+    if packed.padded:
+        for gw, gb, pw, pb in zip(out_w, out_b, grad_weights, grad_biases):
+            if accumulate:
+                gw.add_(pw[:gw.shape[0], :gw.shape[1]])
+                gb.add_(pb[:gb.shape[0]])
+            else:
+                gw.copy_(pw[:gw.shape[0], :gw.shape[1]])
+                gb.copy_(pb[:gb.shape[0]])
 
 
 AIA_WAVELENGTHS = (94, 131, 171, 193, 211, 304, 335)

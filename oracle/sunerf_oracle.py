@@ -208,14 +208,17 @@ def emission_integral(raw: torch.Tensor, z_vals: torch.Tensor, rays_d: torch.Ten
     return {'image': image, 'weights': weights, 'regularizing_quantity': absorption}
 
 
-def render_pass(params: Params, rays_o, rays_d, times, z_vals, half: bool = False) -> Dict[str, torch.Tensor]:
+def render_pass(params: Params, rays_o, rays_d, times, z_vals, half: bool = False, encoding: bool = True) -> Dict[str, torch.Tensor]:
     """One coarse or fine pass: time concat (base_tracing.py:64-65, :83-84), ``_render`` (:118-129, D1
     resolved) and the emission integral.  ``half``: the MLP in the emulated HALF arithmetic (``mlp_forward_half``)."""
     pts = points_on_rays(rays_o, rays_d, z_vals)
     exp_times = times[:, None].repeat(1, pts.shape[1], 1)
     query = torch.cat([pts, exp_times], -1)
-    mlp = mlp_forward_half if half else mlp_forward
-    raw = mlp(params, query.view(-1, 4)).reshape(*query.shape[:-1], -1)
+    if half:
+        raw = mlp_forward_half(params, query.view(-1, 4))
+    else:
+        raw = mlp_forward(params, query.view(-1, 4), encoding=encoding)     # encoding=False: NeRF(encoding=None), model.py:32-33
+    raw = raw.reshape(*query.shape[:-1], -1)
     out = emission_integral(raw, z_vals, rays_d)
     out['raw'] = raw
     out['points'] = pts
@@ -226,7 +229,7 @@ def render_emission(coarse: Params, fine: Params, rays_o, rays_d, times, *, Rs_p
                     n_coarse: int = 64, n_fine: int = 128, distance: float = 1.3,
                     sampler: str = 'stratified', t_vals: Optional[torch.Tensor] = None,
                     t_rand: Optional[torch.Tensor] = None,
-                    z_vals_combined: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                    z_vals_combined: Optional[torch.Tensor] = None, encoding: bool = True) -> Dict[str, torch.Tensor]:
     """SuNeRFRendering.forward, base_tracing.py:46-111, for the emission subclass.
 
     ``z_vals_combined`` lets a test feed the fine pass with externally supplied sample positions
@@ -236,11 +239,11 @@ def render_emission(coarse: Params, fine: Params, rays_o, rays_d, times, *, Rs_p
     solar_R = torch.tensor(1 / Rs_per_ds, dtype=torch.float32)
     zfn = stratified_z if sampler == 'stratified' else spherical_z
     z_vals = zfn(rays_o, rays_d, t_vals, dist_buf, solar_R, t_rand)
-    c = render_pass(coarse, rays_o, rays_d, times, z_vals)
+    c = render_pass(coarse, rays_o, rays_d, times, z_vals, encoding=encoding)
     new_z, z_comb = hierarchical_z(z_vals, c['weights'], n_fine)
     if z_vals_combined is not None:
         z_comb = z_vals_combined
-    f = render_pass(fine, rays_o, rays_d, times, z_comb)
+    f = render_pass(fine, rays_o, rays_d, times, z_comb, encoding=encoding)
     absorption = f['regularizing_quantity']
     dist_pts = f['points'].pow(2).sum(-1).pow(0.5)
     return {

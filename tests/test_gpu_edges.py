@@ -130,7 +130,58 @@ def test_training_batch_properties(ops):
 def test_unsupported_width_is_a_clear_error():
     from sunerf.model.model import NeRF
     with pytest.raises(ValueError, match='d_filter'):
-        NeRF(d_filter=384)
+        NeRF(d_filter=640)
+    with pytest.raises(ValueError, match='d_input'):
+        NeRF(d_input=3)
+
+
+@pytest.mark.parametrize('d_filter,encoding', [(100, 'positional'), (200, None), (48, 'none'), (320, 'positional')])
+def test_any_width_and_no_encoding_by_exact_zero_padding(d_filter, encoding):
+    """Generality of NeRF (model.py:16-17, 28-33): any d_filter, and `encoding` other than 'positional' (first layer on the raw
+    coordinates).  Both run on the compiled widths by zero padding, which changes no value: forward against the oracle at the
+    north-star gate, all parameter gradients at 1e-3, state-dict keys as the reference module tree."""
+    from conftest import gate_units
+    from sunerf.rendering.emission import EmissionRadiativeTransfer
+    torch.manual_seed(d_filter)
+    mod = EmissionRadiativeTransfer(Rs_per_ds=1.0, sampling_config={'type': 'stratified', 'n_samples': 32, 'perturb': False},
+                                    hierarchical_sampling_config={'type': 'hierarchical', 'n_samples': 32},
+                                    model_config={'d_filter': d_filter, 'n_layers': 4, 'encoding': encoding})
+    positional = encoding == 'positional'
+    keys = set(mod.coarse_model.state_dict())
+    assert ('in_layer.1.weight' in keys) == positional and ('in_layer.weight' in keys) == (not positional)
+    assert mod.coarse_model.linears()[0].weight.shape == (d_filter, 84 if positional else 4)
+    with torch.no_grad():       # raw coordinates are O(1): keep the pre-activations of the un-encoded variant in a sane range
+        for m in (mod.coarse_model, mod.fine_model):
+            m.out_layer.weight.mul_(3.0)
+    o, d = orc.synthetic_rays(5)
+    t = torch.rand(o.shape[0], 1)
+    sd = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+
+    def params_of(prefix):
+        first = 'in_layer.1' if positional else 'in_layer'
+        p = [(sd[f'{prefix}{first}.weight'], sd[f'{prefix}{first}.bias'])]
+        p += [(sd[f'{prefix}layers.{i}.weight'], sd[f'{prefix}layers.{i}.bias']) for i in range(3)]
+        return p + [(sd[f'{prefix}out_layer.weight'], sd[f'{prefix}out_layer.bias'])]
+    leaves = {m: [(W.clone().requires_grad_(True), b.clone().requires_grad_(True)) for W, b in params_of(m)]
+              for m in ('coarse_model.', 'fine_model.')}
+    want = orc.render_emission(leaves['coarse_model.'], leaves['fine_model.'], o, d, t, n_coarse=32, n_fine=32,
+                               t_vals=sd['sampler.t_vals'], encoding=positional)
+    target = torch.rand(o.shape[0], 1, generator=torch.Generator().manual_seed(1))
+    loss_ref = ((want['coarse_image'] - target) ** 2).mean() + ((want['fine_image'] - target) ** 2).mean() + want['regularization'].mean()
+    loss_ref.backward()
+    mod = mod.cuda()
+    got = mod(o.cuda(), d.cuda(), t.cuda())
+    assert mod.coarse_model.packed().padded and mod.coarse_model.packed().d_filter in (64, 128, 256, 512)
+    for k in ('coarse_image', 'fine_image', 'height_map'):
+        assert gate_units(got[k], want[k].detach()) <= 1.0, k
+    loss = ((got['coarse_image'] - target.cuda()) ** 2).mean() + ((got['fine_image'] - target.cuda()) ** 2).mean() + got['regularization'].mean()
+    loss.backward()
+    for m in ('coarse_model', 'fine_model'):
+        for lin, (W, b) in zip(getattr(mod, m).linears(), leaves[m + '.']):
+            assert lin.weight.grad.shape == W.shape
+            eW = ((lin.weight.grad.cpu() - W.grad).norm() / W.grad.norm()).item()
+            eb = ((lin.bias.grad.cpu() - b.grad).norm() / b.grad.norm()).item()
+            assert eW < (3e-3 if m == 'fine_model' else 1e-3) and eb < (3e-3 if m == 'fine_model' else 1e-3), (m, eW, eb)
 
 
 @pytest.mark.parametrize('n_layers,S', [(8, 64), (2, 32), (3, 40)])
