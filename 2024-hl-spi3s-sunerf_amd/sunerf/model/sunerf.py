@@ -228,6 +228,7 @@ def fit_steps(module: BaseSuNeRFModule, batches, gradient_clip_val=0.5):
     (run_emission.py:65-75): backward, clip_grad_norm_(0.5), Adam step, on_train_batch_end."""
     (optimizer,), _ = module.configure_optimizers()
     optimizer.max_norm = gradient_clip_val          # clip fused into the optimiser step (norm and coefficient stay on device)
+    optimizer.overlap = True                        # one backward per model and step here: reduce the fine model's slice early
     losses = []
     for i, batch in enumerate(batches):
         optimizer.zero_grad()

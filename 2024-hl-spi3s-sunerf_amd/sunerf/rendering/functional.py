@@ -34,6 +34,14 @@ def _grad_targets(params):
     return grads[0::2], grads[1::2]
 
 
+def _announce(params):
+    """The gradients of ``params`` are final in their flat bucket: let its owner start the all-reduce of that slice while the
+    other model's backward still runs (``ClipAdam(overlap=True)``)."""
+    owner = getattr(params[0], '_sunerf_bucket', None)
+    if owner is not None:
+        owner[0].segment_ready(params)
+
+
 class _EmissionPass(torch.autograd.Function):
     """One fused render pass (coarse or fine) as an autograd node.
 
@@ -78,6 +86,7 @@ class _EmissionPass(torch.autograd.Function):
         if direct is not None:
             ops.emission_render_bwd(ctx.packed, rays_o, rays_d, z_vals, raw, stash, g_image, g_reg, 0.0, ctx.reg_radius,
                                     direct[0], direct[1], accumulate=True)
+            _announce(ctx.params)
             return (None,) * (7 + ctx.n_params)
         gW = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[0::2]]
         gb = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[1::2]]
@@ -204,6 +213,7 @@ class _DtPass(torch.autograd.Function):
         direct = _grad_targets(ctx.mlp_params)
         if direct is not None:
             ops.mlp_backward(ctx.packed, g_raw, absmax, stash, direct[0], direct[1], accumulate=True)
+            _announce(ctx.mlp_params)
             return head + (None,) * len(ctx.mlp_params)
         gW = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[0::2]]
         gb = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[1::2]]

@@ -104,7 +104,8 @@ class ClipAdam(torch.optim.Optimizer):
     ``param_groups`` carries ``lr`` / ``betas`` / ``eps`` like torch's Adam, so ``ExponentialLR`` (sunerf.py:32) works
     unchanged.  ``max_norm=None`` leaves clipping to the caller (e.g. Lightning's ``gradient_clip_val``)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm: Optional[float] = None, group=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm: Optional[float] = None, group=None,
+                 overlap: bool = False):
         params = [p for p in params]
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         if len(self.param_groups) != 1:
@@ -112,6 +113,12 @@ class ClipAdam(torch.optim.Optimizer):
         self.max_norm = max_norm
         self.group = group
         self.reduce_single_rank = False     # tests: issue the collective even in a one-rank group (exercises RCCL on one GPU)
+        # overlap: the backward of the fine model finishes before the coarse model's starts (the two graphs
+        # are independent, sampling.py:120), so its slice of the bucket can be all-reduced -- asynchronously, on the
+        # collective's own stream -- while the coarse backward kernels still run.  Needs exactly ONE backward per model and
+        # step (no gradient accumulation over micro-batches): opt-in.
+        self.overlap = overlap
+        self._early = []                    # [(lo, hi, work)] slices already handed to the collective this step
         self._params = [p for p in self.param_groups[0]['params'] if p.requires_grad]
         if not self._params:
             raise ValueError('no trainable parameters')
@@ -140,6 +147,7 @@ class ClipAdam(torch.optim.Optimizer):
             self._grad_views.append(gv)
             self.state[p] = {'step': torch.tensor(0.), 'exp_avg': self.exp_avg[off:off + k].view_as(p),
                              'exp_avg_sq': self.exp_avg_sq[off:off + k].view_as(p)}
+            p._sunerf_bucket = (self, off, k)      # lets the backward node announce a finished slice (segment_ready)
             off += k
 
     @property
@@ -151,8 +159,30 @@ class ClipAdam(torch.optim.Optimizer):
         """Zeroes the flat gradient bucket and re-attaches the views (``set_to_none`` is ignored: the backward kernels
         and the all-reduce work in place on the bucket)."""
         self.bucket.zero_()
+        self._early = []
         for p, gv in zip(self._params, self._grad_views):
             p.grad = gv
+
+    def _world(self) -> int:
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size(self.group)
+            if world > 1 or self.reduce_single_rank:
+                return world
+        return 0
+
+    def segment_ready(self, params) -> None:
+        """Called by a backward node whose kernels have accumulated the FINAL gradients of ``params`` into the bucket: starts
+        the all-reduce of that slice right away (``overlap=True`` and a process group; no-op otherwise).  The collective is
+        ordered behind the gradient kernels on the current stream and runs beside whatever is launched next."""
+        if not self.overlap or not self._world():
+            return
+        spans = sorted(p._sunerf_bucket[1:] for p in params)
+        lo, hi = spans[0][0], spans[-1][0] + spans[-1][1]
+        contiguous = sum(k for _, k in spans) == hi - lo
+        clash = any(a < hi and lo < b for a, b, _ in self._early)
+        if not contiguous or clash:
+            return        # not one slice of the bucket, or overlapping an earlier one: leave it to step()
+        self._early.append((lo, hi, dist.all_reduce(self.bucket[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
     def _collect(self):
         for p, gv in zip(self._params, self._grad_views):   # autograd may have put a fresh tensor into .grad
@@ -170,11 +200,18 @@ class ClipAdam(torch.optim.Optimizer):
             self.nonfinite.copy_(skip_if_positive.reshape(1))
         else:
             self.nonfinite.zero_()
-        world = 1
-        if dist.is_available() and dist.is_initialized():
-            world = dist.get_world_size(self.group)
-            if world > 1 or self.reduce_single_rank:
-                dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
+        world = self._world()
+        if world:
+            # what segment_ready has not already sent: the remaining slices of the bucket, the last one with the count
+            done, pos = sorted((lo, hi) for lo, hi, _ in self._early), 0
+            for lo, hi in done + [(self.n_params + 1, self.n_params + 1)]:
+                if lo > pos:
+                    dist.all_reduce(self.bucket[pos:min(lo, self.n_params + 1)], op=dist.ReduceOp.SUM, group=self.group)
+                pos = max(pos, hi)
+            for _, _, work in self._early:
+                work.wait()                 # orders the current stream behind the early collectives
+            self._early = []
+        world = max(world, 1)
         g = self.param_groups[0]
         dev = self.flat_params.device
         ws = _workspace(dev)

@@ -35,10 +35,18 @@ def _batch():
     return o, d, torch.rand(64, 1, generator=gen).cuda(), torch.rand(64, 1, generator=gen).cuda()
 
 
-def _train(rendering, o, d, t, target, group_active, steps=STEPS):
+def _train(rendering, o, d, t, target, group_active, steps=STEPS, overlap=False):
     from sunerf_hip.train import ClipAdam, training_loss
-    opt = ClipAdam(rendering.parameters(), lr=1e-3, max_norm=0.5)
+    opt = ClipAdam(rendering.parameters(), lr=1e-3, max_norm=0.5, overlap=overlap)
     opt.reduce_single_rank = True
+    early = []
+    real_ready = opt.segment_ready
+
+    def spy(params):
+        real_ready(params)
+        early.append(len(opt._early))
+    opt.segment_ready = spy
+    _train.early = early
     for _ in range(steps):
         opt.zero_grad()
         out = rendering(o, d, t)
@@ -58,7 +66,11 @@ def _worker(rank, world, port, out_dir):
     o, d, t, target = _batch()
     b, e = shard_range(o.shape[0], rank, world)
     params, norm = _train(_module(), o[b:e].contiguous(), d[b:e].contiguous(), t[b:e].contiguous(), target[b:e].contiguous(), True)
-    torch.save({'params': params, 'norm': norm}, os.path.join(out_dir, f'rank{rank}.pt'))
+    # the same with the fine model's slice of the bucket all-reduced as soon as its backward has finished (overlap=True)
+    params_o, norm_o = _train(_module(), o[b:e].contiguous(), d[b:e].contiguous(), t[b:e].contiguous(), target[b:e].contiguous(),
+                              True, overlap=True)
+    torch.save({'params': params, 'norm': norm, 'params_overlap': params_o, 'norm_overlap': norm_o, 'early': _train.early},
+               os.path.join(out_dir, f'rank{rank}.pt'))
     dist.destroy_process_group()
 
 
@@ -70,6 +82,11 @@ def test_two_rank_fused_step_equals_single_process(tmp_path):
     for a, b in zip(r0['params'], r1['params']):
         assert torch.equal(a, b)                                 # replicas stay bit-identical
     assert torch.equal(r0['norm'], r1['norm'])
+    # overlapped reduction: two slices went out early in every step (fine model first, then coarse), same sums bit for bit
+    assert r0['early'] == [1, 2] * STEPS, r0['early']
+    assert torch.equal(r0['norm_overlap'], r0['norm'])
+    for a, b in zip(r0['params_overlap'], r0['params']):
+        assert torch.equal(a, b)
     _setup_paths()
     o, d, t, target = _batch()
     init = [p.detach().cpu().clone() for p in _module().parameters()]
