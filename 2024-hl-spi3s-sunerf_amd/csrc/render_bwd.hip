@@ -405,8 +405,13 @@ __global__ __launch_bounds__(DG_THREADS, 1) void dgrad_pair_kernel(DgradArgs a) 
           for (int s = 0; s < PS; ++s) {
             const int ks = hb * PS + s;
             const int r = ks % PF;
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(flo[r], x0[ks], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(flo[r], x1[ks], acc1, 0, 0, 0);
+#ifndef SUNERF_DBG_DGRAD_HI_ONLY
+#define SUNERF_DBG_DGRAD_HI_ONLY 0     // experiment: single fp16 W^T (systematic 2^-12 weight error, see the header comment)
+#endif
+            if (!SUNERF_DBG_DGRAD_HI_ONLY) {
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(flo[r], x0[ks], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(flo[r], x1[ks], acc1, 0, 0, 0);
+            }
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fhi[r], x0[ks], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fhi[r], x1[ks], acc1, 0, 0, 0);
             // pending epilogue: tile U-1 of this layer, or (first) the last tile of the layer above, whose output is our x

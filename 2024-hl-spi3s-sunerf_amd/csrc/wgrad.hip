@@ -191,6 +191,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, char* smem, int l
 #pragma unroll
       for (int i = 0; i < QR; ++i) {
         const half8 af = join(alo[i], ahi[i]);
+#ifndef SUNERF_DBG_WGRAD_NOMFMA
+#define SUNERF_DBG_WGRAD_NOMFMA 0     // timing experiments only: stream the stashes, multiply (almost) nothing
+#endif
+        if (!SUNERF_DBG_WGRAD_NOMFMA || (i == 0 && ks == 0))
 #pragma unroll
         for (int j = 0; j < QR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[j], acc[i][j], 0, 0, 0);
         // db = sum over samples of dZ: four v_dot2_f32_f16 against (1, 1) per operand (fp32 accumulate)

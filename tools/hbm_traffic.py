@@ -18,7 +18,8 @@ KERNELS = ('render_fwd_kernel', 'integral_bwd', 'dgrad', 'wgrad_kernel', 'reduce
 
 def last_per_kernel(directory, counter):
     rows = {}
-    for path in glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True):
+    paths = glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True)
+    for path in sorted(paths, key=os.path.getmtime)[-1:]:      # the newest run only (older runs may share the directory)
         with open(path) as f:
             for r in csv.DictReader(f):
                 if r.get('Counter_Name') != counter:
@@ -45,6 +46,7 @@ def main():
                     'doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); bytes')
     data[f'{mode}_bytes_per_step'] = sum(per_kernel.values())
     data[f'{mode}_bytes_per_kernel'] = per_kernel
+    data[f'{mode}_kernel_bytes'] = per_kernel.get('render_fwd_kernel')      # the dominant kernel (bench.py: roofline.traffic)
     data[f'{mode}_fetch_kib_raw'] = fetch
     data[f'{mode}_write_kib_raw'] = write
     data[f'{mode}_config'] = {'rays': int(rays), 'samples': int(samples), 'd_filter': int(d_filter)}
