@@ -13,14 +13,21 @@
 // (wavelength entry <= 0).  The reference's per-wavelength Python loop with two host syncs per channel
 // (density_temperature.py:245-256) becomes one launch.
 //
-// Layout: 8 lanes per ray (lane w < 7: channel w of the row; lane 7: weights / maps), one thread walks the S samples.
+// Layout: 32 lanes per ray, one sample per lane and 32-sample chunk (coalesced reads of raw / z, coalesced writes), the
+// channels looped inside.  Everything sequential along the ray in the reference -- the running optical depth
+// (cumulative_trapezoid), the trapezoid sum of the attenuated emission and, in the backward pass, the suffix sums of the
+// optical-depth gradients -- is a chunk-wise scan over the 32 lanes with a scalar carry from chunk to chunk, like the
+// emission integral (render_fwd.hip, render_bwd.hip).  (The first version walked the samples with ONE thread per ray and
+// channel: 1.2 ms for the backward of 8192 rays x 256 samples x 7 channels, 10 % of a config-5 training step.)
 #include "sunerf_common.h"
 #include "../../include/sunerf_hip.h"
 
 namespace {
 
-constexpr int DT_THREADS = 64;      // 8 rays per block
+constexpr int DT_THREADS = 256;
+constexpr int DT_RAYS = DT_THREADS / 32;      // rays per workgroup
 constexpr int NCH = 7;
+constexpr int NTAB = NCH * 101;
 
 struct DtArgs {
   const float* raw;          // (N,S,2) MLP output
@@ -71,180 +78,261 @@ __device__ __forceinline__ void response(const float* lt, const float* rs, float
   val = y0 + (x - x0) * (y1 - y0) / (x1 - x0);
 }
 
+__device__ __forceinline__ float scan_up32(float v, int n) {      // inclusive prefix sum over the 32 lanes of a ray
+#pragma unroll
+  for (int d = 1; d < 32; d <<= 1) {
+    const float o = __shfl_up(v, d, 32);
+    if (n >= d) v += o;
+  }
+  return v;
+}
+__device__ __forceinline__ float scan_down32(float v, int n) {    // inclusive suffix sum
+#pragma unroll
+  for (int d = 1; d < 32; d <<= 1) {
+    const float o = __shfl_down(v, d, 32);
+    if (n + d < 32) v += o;
+  }
+  return v;
+}
+__device__ __forceinline__ float sum32(float v) {
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 32);
+  return v;
+}
+
+// channel set-up of one ray (lane-uniform): table rows, absorption coefficient
+struct Channels {
+  int ch[NCH];
+  float kappa[NCH];
+  __device__ __forceinline__ void init(const DtArgs& a, int64_t ray) {
+#pragma unroll
+    for (int w = 0; w < NCH; ++w) {
+      ch[w] = w < a.W ? channel_of(a.wavelengths[ray * a.W + w]) : -1;
+      kappa[w] = ch[w] >= 0 ? fmaxf(a.log_abs[ch[w]], 0.f) : 0.f;
+    }
+  }
+};
+
+// One forward sweep along the ray: per channel the optical depth A_i = cumulative_trapezoid(rho kappa, z) and the trapezoid
+// sum of term_j = exp(-A_{j+1}) rho_j^2 R(logT_j), j = 0..S-2 (density_temperature.py:261-265).  `ea` (backward only):
+// receives exp(-A_{j+1}) at [j * NCH + w].  Returns the trapezoid sums (x 2, as the reference's running sum) in trap[].
+template <bool KEEP>
+__device__ __forceinline__ void forward_sweep(const DtArgs& a, const float* tab, const Channels& C, const float* r, const float* z,
+                                              int n, float* ea, float trap[NCH]) {
+  const int S = a.S, n_chunks = (S + 31) >> 5;
+  float A_c[NCH], ab_c[NCH], e_c[NCH], T_c[NCH];
+#pragma unroll
+  for (int w = 0; w < NCH; ++w) { A_c[w] = ab_c[w] = e_c[w] = T_c[w] = 0.f; trap[w] = 0.f; }
+  float z_c1 = 0.f, z_c2 = 0.f;
+  for (int c = 0; c < n_chunks; ++c) {
+    const int i = 32 * c + n;
+    const bool valid = i < S;
+    const int ii = valid ? i : S - 1;
+    const float zi = z[ii];
+    const f32x2 rr = *(const f32x2*)(r + 2 * ii);
+    float zp = __shfl_up(zi, 1, 32);
+    if (n == 0) zp = z_c1;
+    float zpp = __shfl_up(zp, 1, 32);
+    if (n == 0) zpp = z_c2;
+    const float rho = expf(fmaxf(rr[0] + a.base_rho, 0.f));
+    const float logt = fmaxf(rr[1] + a.base_t, 0.f);
+#pragma unroll
+    for (int w = 0; w < NCH; ++w) {
+      if (w >= a.W) break;
+      float R = 0.f, dR;
+      if (C.ch[w] >= 0) response(tab + C.ch[w] * 101, tab + NTAB + C.ch[w] * 101, logt, R, dR);
+      const float ab = rho * C.kappa[w], e = rho * rho * R;
+      float abp = __shfl_up(ab, 1, 32), ep = __shfl_up(e, 1, 32);
+      if (n == 0) { abp = ab_c[w]; ep = e_c[w]; }
+      const float inc = (valid && i >= 1) ? (ab + abp) * (zi - zp) / 2.f : 0.f;     // ((y1 + y0) * dx) / 2
+      const float A = A_c[w] + scan_up32(inc, n);
+      const float ex = expf(-A);
+      if (KEEP && valid && i >= 1) ea[(size_t)(i - 1) * NCH + w] = ex;
+      const float T = (valid && i >= 1) ? ex * ep : 0.f;                            // term_{i-1}
+      float Tp = __shfl_up(T, 1, 32);
+      if (n == 0) Tp = T_c[w];
+      if (valid && i >= 2) trap[w] += (T + Tp) * (zp - zpp);
+      A_c[w] = __shfl(A, 31, 32); ab_c[w] = __shfl(ab, 31, 32); e_c[w] = __shfl(e, 31, 32); T_c[w] = __shfl(T, 31, 32);
+    }
+    z_c2 = __shfl(zp, 31, 32);
+    z_c1 = __shfl(zi, 31, 32);
+  }
+#pragma unroll
+  for (int w = 0; w < NCH; ++w) trap[w] = sum32(trap[w]);
+}
+
 __global__ __launch_bounds__(DT_THREADS) void dt_integral_fwd_kernel(DtArgs a) {
-  const int tid = threadIdx.x, sub = tid & 7;
-  const int64_t ray = (int64_t)blockIdx.x * 8 + (tid >> 3);
-  if (ray >= a.n_rays) return;
-  const int S = a.S;
+  __shared__ float tab[2 * NTAB];
+  const int tid = threadIdx.x, n = tid & 31, sub = tid >> 5;
+  for (int i = tid; i < NTAB; i += DT_THREADS) { tab[i] = a.table_logt[i]; tab[NTAB + i] = a.table_resp[i]; }
+  __syncthreads();
+  const int64_t ray = (int64_t)blockIdx.x * DT_RAYS + sub;
+  if (ray >= a.n_rays) return;                     // (a whole 32-lane group leaves: the shuffles are 32 wide)
+  const int S = a.S, n_chunks = (S + 31) >> 5;
   const float* z = a.z_vals + ray * S;
   const float* r = a.raw + ray * S * 2;
-  if (sub < NCH) {
-    if (sub >= a.W) return;
-    const int ch = channel_of(a.wavelengths[ray * a.W + sub]);
-    const float kappa = ch >= 0 ? fmaxf(a.log_abs[ch], 0.f) : 0.f;
-    const float* lt = a.table_logt + (ch >= 0 ? ch : 0) * 101;
-    const float* rs = a.table_resp + (ch >= 0 ? ch : 0) * 101;
-    float A = 0.f, ab_prev = 0.f, e_prev = 0.f, term_prev = 0.f, z_prev = 0.f, z_prev2 = 0.f, trap = 0.f;
-    for (int i = 0; i < S; ++i) {
-      const float rho = expf(fmaxf(r[2 * i] + a.base_rho, 0.f));
-      const float logt = fmaxf(r[2 * i + 1] + a.base_t, 0.f);
-      float R = 0.f, dR;
-      if (ch >= 0) response(lt, rs, logt, R, dR);
-      const float ab = rho * kappa, e = rho * rho * R, zi = z[i];
-      if (i >= 1) {
-        A += (ab + ab_prev) * (zi - z_prev) / 2.f;          // cumulative_trapezoid: ((y1 + y0) * dx) / 2, running sum
-        const float term = expf(-A) * e_prev;               // term_{i-1} = exp(-A_{i-1}) * emission_{i-1}
-        if (i >= 2) trap += (term + term_prev) * (z_prev - z_prev2);
-        term_prev = term;
-      }
-      ab_prev = ab; e_prev = e; z_prev2 = z_prev; z_prev = zi;
+  Channels C;
+  C.init(a, ray);
+  float trap[NCH];
+  forward_sweep<false>(a, tab, C, r, z, n, nullptr, trap);
+  if (n < a.W) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NCH; ++w) if (w == n) t = trap[w];
+    a.image[ray * a.W + n] = t / 2.f * a.vol_c[0] * a.pixel_factor;              // trapezoid: sum((y1 + y0) * dx) / 2
+  }
+  // weights = relu(inf0) / (sum + 1e-10), maps, regularization (density_temperature.py:268-274)
+  const float ox = a.rays_o[ray * 3 + 0], oy = a.rays_o[ray * 3 + 1], oz = a.rays_o[ray * 3 + 2];
+  const float dx = a.rays_d[ray * 3 + 0], dy = a.rays_d[ray * 3 + 1], dz = a.rays_d[ray * 3 + 2];
+  float sum = 0.f;
+  for (int c = 0; c < n_chunks; ++c) {
+    const int i = 32 * c + n;
+    if (i < S) sum += fmaxf(r[2 * i] + a.base_rho, 0.f);
+  }
+  const float denom = sum32(sum) + 1e-10f;
+  float hm = 0.f, am = 0.f;
+  for (int c = 0; c < n_chunks; ++c) {
+    const int i = 32 * c + n;
+    if (i >= S) continue;
+    const float q = fmaxf(r[2 * i] + a.base_rho, 0.f);
+    const float w = q / denom;
+    a.weights[ray * S + i] = w;
+    a.reg_q[ray * S + i] = q;
+    if (a.regularization || a.height_map) {
+      const float zi = z[i];
+      const float px = ox + dx * zi, py = oy + dy * zi, pz = oz + dz * zi;
+      const float pd = sqrtf((px * px + py * py) + pz * pz);
+      hm += w * pd;
+      if (a.regularization) a.regularization[ray * S + i] = fmaxf(pd - a.reg_radius, 0.f) * fmaxf(q, 0.f);
     }
-    a.image[ray * a.W + sub] = trap / 2.f * a.vol_c[0] * a.pixel_factor;   // trapezoid: sum((y1 + y0) * dx) / 2
-  } else {
-    // lane 7: weights = relu(inf0) / (sum + 1e-10), maps, regularization (density_temperature.py:268-274)
-    const float ox = a.rays_o[ray * 3 + 0], oy = a.rays_o[ray * 3 + 1], oz = a.rays_o[ray * 3 + 2];
-    const float dx = a.rays_d[ray * 3 + 0], dy = a.rays_d[ray * 3 + 1], dz = a.rays_d[ray * 3 + 2];
-    float sum = 0.f;
-    for (int i = 0; i < S; ++i) sum += fmaxf(r[2 * i] + a.base_rho, 0.f);
-    const float denom = sum + 1e-10f;
-    float hm = 0.f, am = 0.f;
-    for (int i = 0; i < S; ++i) {
-      const float q = fmaxf(r[2 * i] + a.base_rho, 0.f);
-      const float w = q / denom;
-      a.weights[ray * S + i] = w;
-      a.reg_q[ray * S + i] = q;
-      if (a.regularization || a.height_map) {
-        const float zi = z[i];
-        const float px = ox + dx * zi, py = oy + dy * zi, pz = oz + dz * zi;
-        const float pd = sqrtf((px * px + py * py) + pz * pz);
-        hm += w * pd;
-        if (a.regularization) a.regularization[ray * S + i] = fmaxf(pd - a.reg_radius, 0.f) * fmaxf(q, 0.f);
-      }
-      am += 1.f - q;
-    }
+    am += 1.f - q;
+  }
+  hm = sum32(hm); am = sum32(am);
+  if (n == 0) {
     if (a.height_map) a.height_map[ray] = hm;
     if (a.absorption_map) a.absorption_map[ray] = am;
   }
 }
 
-// backward: same 8-lanes-per-ray layout; lane w keeps exp(-A_j) of its channel in LDS ([S][64]), walks the samples in
-// reverse accumulating the suffix sums of d loss / d A_j; the per-sample raw gradients of the 8 lanes are combined with
-// shuffles (no atomics); log_abs / vol_c gradients are block-reduced and added atomically (7 + 1 values per block).
+// backward: a forward sweep keeps exp(-A_{j+1}) of every channel in LDS ([ray][j][channel]); the reverse sweep forms the
+// suffix sums G_k = sum_{j >= k} dL/dA_j chunk by chunk (descending) and from them the gradients of the two raw outputs of
+// every sample, summed over the channels in the lane (no atomics).  log_abs / vol_c gradients: per-ray lane sums ->
+// workgroup sums in LDS -> 8 atomic adds per workgroup.
 __global__ __launch_bounds__(DT_THREADS) void dt_integral_bwd_kernel(DtArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];    // [S][DT_THREADS] exp(-A_j)
-  const int tid = threadIdx.x, sub = tid & 7;
-  const int64_t ray_raw = (int64_t)blockIdx.x * 8 + (tid >> 3);
+  extern __shared__ __attribute__((aligned(16))) float lds[];    // tables | g_kappa[7] g_vol | [DT_RAYS][S][NCH] exp(-A)
+  float* tab = lds;
+  float* acc8 = lds + 2 * NTAB;
+  const int tid = threadIdx.x, n = tid & 31, sub = tid >> 5;
+  for (int i = tid; i < NTAB; i += DT_THREADS) { tab[i] = a.table_logt[i]; tab[NTAB + i] = a.table_resp[i]; }
+  if (tid < 8) acc8[tid] = 0.f;
+  __syncthreads();
+  const int64_t ray_raw = (int64_t)blockIdx.x * DT_RAYS + sub;
   const bool ray_ok = ray_raw < a.n_rays;
   const int64_t ray = ray_ok ? ray_raw : a.n_rays - 1;
-  const int S = a.S;
+  const int S = a.S, n_chunks = (S + 31) >> 5;
+  float* ea = lds + 2 * NTAB + 8 + (size_t)sub * S * NCH;
   const float* z = a.z_vals + ray * S;
   const float* r = a.raw + ray * S * 2;
-  const bool chan_lane = sub < NCH && sub < a.W && ray_ok;
-  int ch = -1;
-  float kappa = 0.f, g_I = 0.f;
-  if (chan_lane) {
-    ch = channel_of(a.wavelengths[ray * a.W + sub]);
-    kappa = ch >= 0 ? fmaxf(a.log_abs[ch], 0.f) : 0.f;
-    g_I = a.g_image[ray * a.W + sub];
+  Channels C;
+  C.init(a, ray);
+  float trap[NCH];
+  forward_sweep<true>(a, tab, C, r, z, n, ea, trap);
+  float g_trap[NCH], g_kappa[NCH], G_c[NCH];
+  const float Cf = a.vol_c[0] * a.pixel_factor;
+#pragma unroll
+  for (int w = 0; w < NCH; ++w) {
+    g_trap[w] = (ray_ok && w < a.W) ? a.g_image[ray * a.W + w] * Cf : 0.f;
+    g_kappa[w] = 0.f;
+    G_c[w] = 0.f;
   }
-  const float* lt = a.table_logt + (ch >= 0 ? ch : 0) * 101;
-  const float* rs = a.table_resp + (ch >= 0 ? ch : 0) * 101;
-  const float C = a.vol_c[0] * a.pixel_factor;
-  // ---- forward sweep: exp(-A_j) for j = 0..S-2, and the trapezoid value (for d/d vol_c) ----
-  float trap = 0.f;
-  if (chan_lane) {
-    float A = 0.f, ab_prev = 0.f, e_prev = 0.f, term_prev = 0.f, z_prev = 0.f, z_prev2 = 0.f;
-    for (int i = 0; i < S; ++i) {
-      const float rho = expf(fmaxf(r[2 * i] + a.base_rho, 0.f));
-      const float logt = fmaxf(r[2 * i + 1] + a.base_t, 0.f);
-      float R = 0.f, dR;
-      if (ch >= 0) response(lt, rs, logt, R, dR);
-      const float ab = rho * kappa, e = rho * rho * R, zi = z[i];
-      if (i >= 1) {
-        A += (ab + ab_prev) * (zi - z_prev) / 2.f;
-        const float ea = expf(-A);
-        lds[(i - 1) * DT_THREADS + tid] = ea;
-        const float term = ea * e_prev;
-        if (i >= 2) trap += (term + term_prev) * (z_prev - z_prev2);
-        term_prev = term;
-      }
-      ab_prev = ab; e_prev = e; z_prev2 = z_prev; z_prev = zi;
-    }
-    trap *= 0.5f;
-  }
-  const float g_trap = g_I * C;
-  float g_kappa = 0.f;
-  // geometry for the regularization gradient (lane 7)
   const float ox = a.rays_o[ray * 3 + 0], oy = a.rays_o[ray * 3 + 1], oz = a.rays_o[ray * 3 + 2];
   const float dx = a.rays_d[ray * 3 + 0], dy = a.rays_d[ray * 3 + 1], dz = a.rays_d[ray * 3 + 2];
-  // ---- reverse sweep over k = S-1 .. 0 ----
-  float G = 0.f;            // G_k = sum_{j >= k} g_A_j  (G_{S-1} = 0)
   float local_max = 0.f;
-  for (int k = S - 1; k >= 0; --k) {
-    const float raw0 = r[2 * k], raw1 = r[2 * k + 1];
-    const float inf0 = raw0 + a.base_rho, inf1 = raw1 + a.base_t;
+  // trapezoid weight of term_j on the grid z[0..S-2]:  wt_j = (dz_{j-1} + dz_j) / 2 with missing neighbours dropped
+  auto wt = [&](int j, float zm, float z0, float zp1) {
+    float w = 0.f;
+    if (j >= 1) w += z0 - zm;
+    if (j <= S - 3) w += zp1 - z0;
+    return 0.5f * w;
+  };
+  for (int c = n_chunks - 1; c >= 0; --c) {
+    const int k = 32 * c + n;
+    const bool valid = k < S;
+    const int kk = valid ? k : S - 1;
+    const float zk = z[kk], zm = z[kk >= 1 ? kk - 1 : 0], zp1 = z[kk + 1 < S ? kk + 1 : S - 1];
+    const f32x2 rr = *(const f32x2*)(r + 2 * kk);
+    const float inf0 = rr[0] + a.base_rho, inf1 = rr[1] + a.base_t;
+    const float rho = expf(fmaxf(inf0, 0.f)), logt = fmaxf(inf1, 0.f);
+    const float wk = wt(kk, zm, zk, zp1);
+    // lane 0 also needs dL/dA of the sample below its chunk (k - 1): its term is recomputed here
+    const bool below = n == 0 && k >= 1;
+    float rho_b = 0.f, logt_b = 0.f, w_b = 0.f;
+    if (below) {
+      const f32x2 rb = *(const f32x2*)(r + 2 * (k - 1));
+      rho_b = expf(fmaxf(rb[0] + a.base_rho, 0.f));
+      logt_b = fmaxf(rb[1] + a.base_t, 0.f);
+      w_b = wt(k - 1, z[k >= 2 ? k - 2 : 0], zm, zk);
+    }
     float g0 = 0.f, g1 = 0.f;
-    if (chan_lane) {
-      const float zk = z[k];
-      // trapezoid weight of term_j on the grid z[0..S-2]:  wt_j = (dz_{j-1} + dz_j) / 2 with missing neighbours dropped
-      auto wt = [&](int j) {
-        float w = 0.f;
-        if (j >= 1) w += z[j] - z[j - 1];
-        if (j <= S - 3) w += z[j + 1] - z[j];
-        return 0.5f * w;
-      };
-      auto point = [&](int j, float& rho, float& R, float& dR) {
-        rho = expf(fmaxf(r[2 * j] + a.base_rho, 0.f));
-        R = 0.f; dR = 0.f;
-        if (ch >= 0) response(lt, rs, fmaxf(r[2 * j + 1] + a.base_t, 0.f), R, dR);
-      };
-      float rho, R, dR;
-      point(k, rho, R, dR);
-      // G_{k-1} = G_k + g_A_{k-1},  g_A_j = -g_term_j * term_j
-      float G_km1 = G;
-      if (k >= 1) {
-        float rho1, R1, dR1;
-        point(k - 1, rho1, R1, dR1);
-        const float term = lds[(k - 1) * DT_THREADS + tid] * rho1 * rho1 * R1;
-        G_km1 = G - g_trap * wt(k - 1) * term;
+#pragma unroll
+    for (int w = 0; w < NCH; ++w) {
+      if (w >= a.W) break;
+      float R = 0.f, dR = 0.f;
+      if (C.ch[w] >= 0) response(tab + C.ch[w] * 101, tab + NTAB + C.ch[w] * 101, logt, R, dR);
+      const bool has_term = valid && k <= S - 2;
+      const float eak = has_term ? ea[(size_t)k * NCH + w] : 0.f;
+      const float gA = has_term ? -g_trap[w] * wk * (eak * rho * rho * R) : 0.f;       // dL/dA_k = -g_term_k * term_k
+      const float G = G_c[w] + scan_down32(gA, n);                                      // G_k = sum_{j >= k} dL/dA_j
+      float gA_b = __shfl_up(gA, 1, 32);                                                 // dL/dA_{k-1}
+      if (n == 0) {
+        gA_b = 0.f;
+        if (below) {
+          float Rb = 0.f, dRb;
+          if (C.ch[w] >= 0) response(tab + C.ch[w] * 101, tab + NTAB + C.ch[w] * 101, logt_b, Rb, dRb);
+          gA_b = -g_trap[w] * w_b * (ea[(size_t)(k - 1) * NCH + w] * rho_b * rho_b * Rb);
+        }
       }
-      float g_ab = 0.f;
-      if (k <= S - 2) g_ab += 0.5f * (z[k + 1] - zk) * G;
-      if (k >= 1) g_ab += 0.5f * (zk - z[k - 1]) * G_km1;
-      float g_e = 0.f;
-      if (k <= S - 2) g_e = g_trap * wt(k) * lds[k * DT_THREADS + tid];
-      const float g_rho = g_ab * kappa + g_e * 2.f * rho * R;
-      g_kappa += g_ab * rho;
-      if (inf0 > 0.f) g0 = g_rho * rho;
-      if (inf1 > 0.f) g1 = g_e * rho * rho * dR;
-      G = G_km1;
-    } else if (sub == 7 && ray_ok) {
+      if (valid) {
+        float g_ab = 0.f;
+        if (k <= S - 2) g_ab += 0.5f * (zp1 - zk) * G;
+        if (k >= 1) g_ab += 0.5f * (zk - zm) * (G + gA_b);                               // G_{k-1}
+        const float g_e = has_term ? g_trap[w] * wk * eak : 0.f;
+        const float g_rho = g_ab * C.kappa[w] + g_e * 2.f * rho * R;
+        g_kappa[w] += g_ab * rho;
+        if (inf0 > 0.f) g0 += g_rho * rho;
+        if (inf1 > 0.f) g1 += g_e * rho * rho * dR;
+      }
+      G_c[w] = __shfl(G, 0, 32);
+    }
+    if (valid && ray_ok) {
       // regularization_k = relu(|p_k| - R) * relu(relu(inf0))
       const float gr = a.g_reg ? a.g_reg[ray * S + k] : 0.f;
       if (gr != 0.f && inf0 > 0.f) {
-        const float zk = z[k];
         const float px = ox + dx * zk, py = oy + dy * zk, pz = oz + dz * zk;
-        g0 = gr * fmaxf(sqrtf((px * px + py * py) + pz * pz) - a.reg_radius, 0.f);
+        g0 += gr * fmaxf(sqrtf((px * px + py * py) + pz * pz) - a.reg_radius, 0.f);
       }
-    }
-    // combine the 8 lanes of the ray
-#pragma unroll
-    for (int d = 1; d < 8; d <<= 1) { g0 += __shfl_xor(g0, d, 8); g1 += __shfl_xor(g1, d, 8); }
-    if (sub == 0 && ray_ok) {
-      a.g_raw[(ray * S + k) * 2 + 0] = g0;
-      a.g_raw[(ray * S + k) * 2 + 1] = g1;
+      const f32x2 gg = {g0, g1};
+      *(f32x2*)(a.g_raw + ((size_t)ray * S + k) * 2) = gg;
       local_max = fmaxf(local_max, fmaxf(fabsf(g0), fabsf(g1)));
     }
   }
   // ---- parameter gradients: log_abs (through kappa = relu(log_abs)) and vol_c ----
-  if (chan_lane && ch >= 0) {
-    if (a.log_abs[ch] > 0.f && g_kappa != 0.f) atomicAdd(a.g_log_abs + ch, g_kappa);
-    const float gv = g_I * trap * a.pixel_factor;
-    if (gv != 0.f) atomicAdd(a.g_vol_c, gv);
+  float g_vol = 0.f;
+#pragma unroll
+  for (int w = 0; w < NCH; ++w) {
+    const float gk = sum32(g_kappa[w]);
+    if (n == 0 && ray_ok && w < a.W && C.ch[w] >= 0) {
+      if (a.log_abs[C.ch[w]] > 0.f && gk != 0.f) atomicAdd(acc8 + C.ch[w], gk);
+      g_vol += a.g_image[ray * a.W + w] * (0.5f * trap[w]) * a.pixel_factor;
+    }
   }
+  if (n == 0 && g_vol != 0.f) atomicAdd(acc8 + 7, g_vol);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, d));
-  if (tid == 0 && local_max > 0.f && local_max < INFINITY) atomicMax(a.g_absmax_bits, __float_as_uint(local_max));
+  __syncthreads();
+  if (tid < NCH && acc8[tid] != 0.f) atomicAdd(a.g_log_abs + tid, acc8[tid]);
+  if (tid == 7 && acc8[7] != 0.f) atomicAdd(a.g_vol_c, acc8[7]);
+  if ((tid & 63) == 0 && local_max > 0.f && local_max < INFINITY) atomicMax(a.g_absmax_bits, __float_as_uint(local_max));
 }
 
 int check_common(const DtArgs& a) {
@@ -325,7 +413,8 @@ extern "C" int sunerf_dt_integral_fwd(const float* raw, const float* z_vals, con
   if (n_rays == 0) return 0;
   if (!image || !weights || !reg_q) return SUNERF_E_BADARG;
   SUNERF_CLEAR_ERROR();
-  hipLaunchKernelGGL(dt_integral_fwd_kernel, dim3((unsigned)((n_rays + 7) / 8)), dim3(DT_THREADS), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(dt_integral_fwd_kernel, dim3((unsigned)((n_rays + DT_RAYS - 1) / DT_RAYS)), dim3(DT_THREADS), 0,
+                     (hipStream_t)stream, a);
   SUNERF_CHECK_LAUNCH();
   return 0;
 }
@@ -350,14 +439,14 @@ extern "C" int sunerf_dt_integral_bwd(const float* raw, const float* z_vals, con
   if ((e = hipMemsetAsync(g_log_abs, 0, NCH * sizeof(float), st)) != hipSuccess) return (int)e;
   if ((e = hipMemsetAsync(g_vol_c, 0, sizeof(float), st)) != hipSuccess) return (int)e;
   if (n_rays == 0) return 0;
-  const size_t lds = (size_t)n_samples * DT_THREADS * sizeof(float);
+  const size_t lds = ((size_t)2 * NTAB + 8 + (size_t)DT_RAYS * n_samples * NCH) * sizeof(float);
   if (lds > 160 * 1024) return SUNERF_E_UNSUPPORTED;
   if (lds > 64 * 1024) {
     e = hipFuncSetAttribute((const void*)dt_integral_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   SUNERF_CLEAR_ERROR();
-  hipLaunchKernelGGL(dt_integral_bwd_kernel, dim3((unsigned)((n_rays + 7) / 8)), dim3(DT_THREADS), lds, st, a);
+  hipLaunchKernelGGL(dt_integral_bwd_kernel, dim3((unsigned)((n_rays + DT_RAYS - 1) / DT_RAYS)), dim3(DT_THREADS), lds, st, a);
   SUNERF_CHECK_LAUNCH();
   return 0;
 }
