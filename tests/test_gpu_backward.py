@@ -158,3 +158,30 @@ def test_backward_saturates_instead_of_overflowing(ops):
     torch.cuda.synchronize()
     assert all(torch.isfinite(g).all() for g in gW + gb)
     assert gW[1].abs().max().item() > 0
+
+
+@pytest.mark.parametrize('d_filter,n_layers', [(256, 8), (64, 3)])
+def test_half_mode_gradients_against_the_fp32_oracle(ops, d_filter, n_layers):
+    """The opt-in HALF arithmetic (single fp16 operands in the forward: the bf16-class arithmetic of BASELINE config 3, with
+    fp16's three extra mantissa bits) in TRAINING: its stash is the fp16 evaluation of the network, its backward the same
+    kernels as the default.  There is no differentiable fp16-emulating oracle, so the gradients are held to the fp32 oracle's
+    autograd: measured 8.5e-4 (8 x 256) and 6.8e-4 (3 x 64) relative L2 on the worst tensor -- the 1e-3 of the default mode
+    without its margin (default: 3e-4), asserted at 1.5e-3.  The forward OUTPUTS of this mode are ~1e-3 from the reference
+    (test_half_precision_follows_emulated_oracle), outside the 1e-4 gate: HALF is never the default and `bench.py` prints its
+    figure only on request (--half)."""
+    params, o, d, t, z = _case(d_filter, n_layers, 64)
+    g_image = torch.randn(o.shape[0]) * 1e-3
+    _, ref_grads, _ = _oracle_grads(params, o, d, t, z, g_image, 2e-5)
+    dev = torch.device('cuda')
+    Ws, bs = [W.to(dev) for W, _ in params], [b.to(dev) for _, b in params]
+    packed = ops.PackedMLP(Ws, bs, precision=ops.PRECISION_HALF)
+    fwd = ops.emission_render_fwd(packed, o.to(dev), d.to(dev), t.to(dev), z.to(dev), reg_radius=1.2, training=True)
+    gW, gb = [torch.full_like(W, float('nan')) for W in Ws], [torch.full_like(b, float('nan')) for b in bs]
+    ops.emission_render_bwd(packed, o.to(dev), d.to(dev), z.to(dev), fwd['raw'], fwd['stash'], g_image.to(dev), None, 2e-5, 1.2,
+                            gW, gb)
+    torch.cuda.synchronize()
+    worst = 0.
+    for (rW, rb), W, b in zip(ref_grads, gW, gb):
+        worst = max(worst, ((W.cpu() - rW).norm() / rW.norm()).item(), ((b.cpu() - rb).norm() / rb.norm()).item())
+    print(f'HALF training gradients, d={d_filter} L={n_layers}: worst relative L2 deviation from the fp32 oracle {worst:.2e}')
+    assert worst < 1.5e-3
