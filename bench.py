@@ -168,8 +168,8 @@ def main():
     ap.add_argument('--batch', type=int, default=32768, help='rays per rank and optimiser step (train mode)')
     ap.add_argument('--mode', choices=['train', 'fwd'], default='train')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--half', action='store_true', help='also time the opt-in HALF arithmetic (single fp16 operands: forward '
-                                                        'parity against an fp16-emulating oracle only; reported under "half_precision")')
+    ap.add_argument('--no-half', action='store_true', help='skip BASELINE config 3 (the same step with single fp16 MFMA operands in '
+                                                           'the forward, reported under "half_precision", never as the headline)')
     ap.add_argument('--no-two-pass', action='store_true', help='skip the reference-shaped two-pass figure (train mode)')
     ap.add_argument('--no-small-batch', action='store_true', help="skip the figure at the reference's own batch of 3072 rays")
     ap.add_argument('--no-dt', action='store_true', help='skip BASELINE config 5: density-temperature head, two-pass, 128 + 256 '
@@ -326,10 +326,11 @@ def main():
         extras['small_batch'] = {'value': 3072 * args.samples * world * ss / e, 'unit': 'ray-samples/s', 'rays_per_step_per_gpu': 3072,
                                  'ms_per_step': e / ss * 1e3, 'steps': ss,
                                  'what': "the same step at the reference's own batch size (config/sunerfs_simple_star.yaml:8)"}
-    if args.half and not half:
-        # opt-in: the same step in the HALF arithmetic (single fp16 MFMA operands, fp32 accumulate -- the "bf16 MLP weights
-        # on MFMA" class of BASELINE config 3).  Never the headline: its forward follows an fp16-emulating oracle to 1e-4, not
-        # the fp32 reference.
+    if not args.no_half and not half:
+        # BASELINE config 3 beside the headline: the same step in the HALF arithmetic (single fp16 MFMA operands, fp32
+        # accumulate -- the "bf16 MLP weights on MFMA" class, with fp16's three extra mantissa bits).  Never the headline: its
+        # forward outputs follow an fp16-emulating oracle to 1e-4 and are ~1e-3 from the fp32 reference; its training
+        # gradients are within 1e-3 of the fp32 oracle (tests/test_gpu_backward.py::test_half_mode_gradients_...: 8.5e-4).
         os.environ['SUNERF_FORWARD_PRECISION'] = 'half'
         model._packed = None
         hs = max(2, args.steps // 2)
@@ -338,9 +339,10 @@ def main():
         model._packed = None
         extras['half_precision'] = {'value': rays_per_step * args.samples * world * hs / e, 'unit': 'ray-samples/s',
                                     'ms_per_step': e / hs * 1e3, 'steps': hs,
-                                    'what': 'the same step with SUNERF_FORWARD_PRECISION=half (opt-in): single fp16 MFMA operands, '
-                                            'fp32 accumulate; forward parity against an fp16-emulating oracle at 1e-4, NOT the fp32 '
-                                            'reference -- reported beside the headline, never as it'}
+                                    'what': 'BASELINE config 3 class: the same step with SUNERF_FORWARD_PRECISION=half (opt-in mode): single '
+                                            'fp16 MFMA operands, fp32 accumulate; forward outputs follow an fp16-emulating oracle at 1e-4 '
+                                            '(~1e-3 from the fp32 reference), training gradients within 1e-3 of the fp32 oracle (measured '
+                                            '8.5e-4) -- reported beside the headline, never as it'}
     if args.mode == 'train' and not args.no_two_pass:      # after the timed region of the headline metric
         del opt, model
         torch.cuda.empty_cache()

@@ -5,7 +5,7 @@ TAG=$1; shift
 OUT=$R/gpurun_out/ks_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --no-cpu-baseline --no-two-pass --no-small-batch --steps 6 --warmup 2 "$@" > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --no-cpu-baseline --no-two-pass --no-small-batch --no-half --steps 6 --warmup 2 "$@" > $OUT/run.log 2>&1
 f=$(find $OUT -name '*kernel_stats.csv' | head -1)
 python3 - "$f" <<'PY'
 import csv, sys

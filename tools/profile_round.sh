@@ -8,7 +8,7 @@ rm -rf "$OUT"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for mode in train fwd; do
-  extra="--no-cpu-baseline --no-two-pass --no-small-batch --steps 3 --warmup 1 --mode $mode"
+  extra="--no-cpu-baseline --no-two-pass --no-small-batch --no-half --steps 3 --warmup 1 --mode $mode"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${mode}_stats -- python3 $R/bench.py $extra > $OUT/${mode}_stats.log 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${mode}_fetch -- python3 $R/bench.py $extra > $OUT/${mode}_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${mode}_write -- python3 $R/bench.py $extra > $OUT/${mode}_write.log 2>&1
