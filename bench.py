@@ -116,7 +116,8 @@ def two_pass_rate(dev, world, rays_o, rays_d, times, target, batch, samples, ste
         target = torch.rand(target.shape[0], 7, generator=torch.Generator().manual_seed(1)).to(dev)
     else:
         rendering = EmissionRadiativeTransfer(**cfg).to(dev)
-    opt = ClipAdam(rendering.parameters(), lr=1e-4, max_norm=0.5)
+    # overlap: the fine model's slice of the bucket is all-reduced while the coarse model's backward runs
+    opt = ClipAdam(rendering.parameters(), lr=1e-4, max_norm=0.5, overlap=True)
     n_batches = max(1, rays_o.shape[0] // batch)
 
     def step(i):

@@ -154,8 +154,8 @@ def _worker_rccl(rank, world, port, out_dir):
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=rank, world_size=world)
     o, d, t, target = _batch()
-    params, norm = _train(_module(), o, d, t, target, True, steps=2)
-    torch.save({'params': params, 'norm': norm}, os.path.join(out_dir, 'rccl.pt'))
+    params, norm = _train(_module(), o, d, t, target, True, steps=2, overlap=True)     # async slices + remainder, through RCCL
+    torch.save({'params': params, 'norm': norm, 'early': _train.early}, os.path.join(out_dir, 'rccl.pt'))
     dist.destroy_process_group()
 
 
@@ -165,6 +165,7 @@ def test_rccl_backend_runs_the_bucket_all_reduce(tmp_path):
     process-group-free step.  The N > 1 exchange itself is covered with gloo above and run by the driver on 8 GPUs."""
     mp.spawn(_worker_rccl, args=(1, 29549, str(tmp_path)), nprocs=1, join=True)
     got = torch.load(tmp_path / 'rccl.pt')
+    assert got['early'] == [1, 2] * 2          # both models' slices went out through the asynchronous path
     _setup_paths()
     o, d, t, target = _batch()
     ref, ref_norm = _train(_module(), o, d, t, target, False, steps=2)
