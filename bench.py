@@ -365,8 +365,8 @@ def main():
         step_ms = elapsed / args.steps * 1e3
         step_achieved = rays_per_step * args.samples * flops_step / (step_ms * 1e-3) / 1e12
         # matrix-pipe work of the forward per algorithmic flop: EXACT 3 fp16 products; FAST 1 fp16 product + two 64-deep
-        # fp8 instructions per four 16-deep steps (measured 84 cycles each against 4 x 32: tools/probes/bench_mfma_mix.hip)
-        fwd_factor = 1.0 if half else (1.0 + 2.0 * 84.0 / 128.0 if fast else 3.0)
+        # fp8 instructions per four 16-deep steps (64 cycles each against 4 x 32: tools/probes/probe_mfma_i8.hip)
+        fwd_factor = 1.0 if half else (1.0 + 2.0 * 64.0 / 128.0 if fast else 3.0)
         traffic = traffic_source = None
         for tname in ('hbm_traffic.json', 'hbm_traffic_d512.json'):
             tpath = os.path.join(ROOT, 'profiles', tname)
