@@ -18,6 +18,17 @@ STAT_KEYS = ('loss', 'coarse', 'fine', 'regularization', 'psnr', 'non_finite')
 _ws = {}      # (device, stream) -> zero-initialised reduction workspace
 
 
+def remaining_slices(done, total):
+    """[lo, hi) pieces of ``[0, total)`` not covered by the (possibly unordered) intervals ``done`` -- what ``ClipAdam.step`` still
+    has to all-reduce after ``segment_ready`` sent some slices of the bucket early."""
+    out, pos = [], 0
+    for lo, hi in sorted(done) + [(total, total)]:
+        if lo > pos:
+            out.append((pos, min(lo, total)))
+        pos = max(pos, hi)
+    return out
+
+
 def _workspace(dev) -> torch.Tensor:
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     ws = _ws.get(key)
@@ -203,11 +214,8 @@ class ClipAdam(torch.optim.Optimizer):
         world = self._world()
         if world:
             # what segment_ready has not already sent: the remaining slices of the bucket, the last one with the count
-            done, pos = sorted((lo, hi) for lo, hi, _ in self._early), 0
-            for lo, hi in done + [(self.n_params + 1, self.n_params + 1)]:
-                if lo > pos:
-                    dist.all_reduce(self.bucket[pos:min(lo, self.n_params + 1)], op=dist.ReduceOp.SUM, group=self.group)
-                pos = max(pos, hi)
+            for lo, hi in remaining_slices([(lo, hi) for lo, hi, _ in self._early], self.n_params + 1):
+                dist.all_reduce(self.bucket[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
             for _, _, work in self._early:
                 work.wait()                 # orders the current stream behind the early collectives
             self._early = []

@@ -55,3 +55,37 @@ def test_two_rank_step_equals_global_batch(tmp_path):
         opt.step()
     for a, b in zip(r0['params'], net.parameters()):
         assert torch.allclose(a, b.detach(), rtol=1e-5, atol=1e-7)
+
+
+def test_remaining_slices_cover_exactly_what_was_not_sent_early():
+    """Interval bookkeeping of the overlapped reduction (ClipAdam.step): early slices + remainder = the whole bucket, once."""
+    sys.path.insert(0, os.path.join(ROOT, '2024-hl-spi3s-sunerf_amd'))
+    from sunerf_hip.train import remaining_slices
+    n = 965636 + 1                                   # two 8 x 256 models + the non-finite count at the tail
+    half = 482818
+    assert remaining_slices([], n) == [(0, n)]
+    assert remaining_slices([(half, 2 * half)], n) == [(0, half), (2 * half, n)]            # fine model went out early
+    assert remaining_slices([(half, 2 * half), (0, half)], n) == [(2 * half, n)]             # both: only the count remains
+    assert remaining_slices([(10, 20), (15, 30), (40, 50)], 60) == [(0, 10), (30, 40), (50, 60)]
+    for done in ([(3, 9), (0, 2)], [(0, 60)], [(59, 60)]):
+        covered = sorted(done + remaining_slices(done, 60))
+        assert covered[0][0] == 0 and covered[-1][1] == 60
+        assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+
+
+def _worker_tail(rank, world, port, out_dir):
+    """The lock-step rule on CPU tensors (what ClipAdam does on the device): every rank appends its own non-finite count to
+    the gradient bucket, ONE sum all-reduce, and the decision is taken on the reduced tail."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    bucket = torch.full((11,), float(rank + 1))
+    bucket[-1] = 1.0 if rank == 1 else 0.0           # only rank 1 saw a NaN
+    dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+    torch.save(bucket, os.path.join(out_dir, f'tail{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_non_finite_count_in_the_bucket_tail_reaches_every_rank(tmp_path):
+    mp.spawn(_worker_tail, args=(2, 29519, str(tmp_path)), nprocs=2, join=True)
+    b0, b1 = torch.load(tmp_path / 'tail0.pt'), torch.load(tmp_path / 'tail1.pt')
+    assert torch.equal(b0, b1) and b0[-1].item() == 1.0 and b0[0].item() == 3.0

@@ -45,6 +45,29 @@ def test_emission_raw2outputs_matches_reference_and_its_gradient():
     assert (raw2.grad.cpu() - leaf.grad).abs().max().item() <= 1e-5 * leaf.grad.abs().max().item() + 1e-9
 
 
+@pytest.mark.parametrize('n_rays,S', [(13, 40), (1, 2), (64, 257), (0, 8)])
+def test_emission_integral_ragged_shapes(n_rays, S):
+    """The stand-alone integral on shapes that are no multiple of anything (rays per workgroup 8, chunk 32): vs the oracle."""
+    from sunerf_hip import ops
+    gen = torch.Generator().manual_seed(S)
+    raw = torch.randn(n_rays, S, 2, generator=gen)
+    z = torch.sort(torch.rand(n_rays, S, generator=gen) * 2.6 + 213.7, dim=-1)[0]
+    d = torch.randn(n_rays, 3, generator=gen)
+    image, weights, absorption = ops.emission_integral_fwd(raw.cuda(), z.cuda(), d.cuda())
+    torch.cuda.synchronize()
+    assert image.shape == (n_rays, 1) and weights.shape == (n_rays, S)
+    if n_rays == 0:
+        return
+    ref = orc.emission_integral(raw, z, d)
+    assert gate_units(image, ref['image']) <= 1.0
+    assert (weights.cpu() - ref['weights']).abs().max().item() <= 1e-5 * ref['weights'].abs().max().item() + 1e-9
+    assert ((absorption.cpu() - ref['regularizing_quantity']).abs() / ref['regularizing_quantity']).max().item() <= 1e-6
+    g_raw = ops.emission_integral_bwd(raw.cuda(), z.cuda(), d.cuda(), g_image=torch.ones(n_rays).cuda())
+    leaf = raw.clone().requires_grad_(True)
+    orc.emission_integral(leaf, z, d)['image'].sum().backward()
+    assert (g_raw.cpu() - leaf.grad).abs().max().item() <= 1e-5 * leaf.grad.abs().max().item() + 1e-12
+
+
 def _dt_module(g, n_c=16, n_f=16, d_filter=64):
     from sunerf.model.model import NeRF_DT
     from sunerf.rendering.density_temperature import DensityTemperatureRadiativeTransfer
