@@ -183,7 +183,9 @@ class _DtPass(torch.autograd.Function):
         training = any(ctx.needs_input_grad[10:])
         ctx.set_materialize_grads(False)
         packed = model.packed()
-        mlp = ops.emission_render_fwd(packed, rays_o, rays_d, times, z_vals, 0.0, want_raw=True, training=training)
+        # (the DT image goes with rho^2 = exp(2 raw_0): twice the emission image's sensitivity to the raw output)
+        mlp = ops.emission_render_fwd(packed, rays_o, rays_d, times, z_vals, 0.0, want_raw=True, training=training,
+                                      probe_sensitivity=2.0)
         out = ops.dt_integral_fwd(mlp['raw'], z_vals, rays_o, rays_d, wavelengths, tables[0], tables[1], la, vol_c,
                                   model.base_log_density, model.base_log_temperature, pixel_factor, reg_radius,
                                   want_epilogues=want_epilogues)

@@ -23,7 +23,7 @@ PRECISION_NAMES = {PRECISION_FAST: 'fast', PRECISION_EXACT: 'exact', PRECISION_H
 # the north-star gate (1e-4 relative) for freshly initialised and for trained networks, but the noise of ANY arithmetic
 # -- the reference's included -- is amplified by the network's conditioning, and with all hidden weights x 4 FAST leaves
 # the gate while EXACT stays inside.  So the mode is chosen by MEASUREMENT: every PROBE_EVERY-th parameter version (and the
-# first) the first PROBE_RAYS rays of the render call at hand are rendered in both modes and compared in gate units,
+# first) PROBE_RAYS rays spread evenly over the render call at hand are rendered in both modes and compared in gate units,
 #     max_ray |fast - exact| / (1e-4 |exact| + 1e-6 max|exact|)      over image, height_map, absorption_map,
 # FAST is kept while that stays below PROBE_LIMIT (the margin covers EXACT's own error and rays outside the probe).
 PROBE_EVERY = 64
@@ -153,15 +153,22 @@ class PackedMLP:
         _l.call(self.device, 'sunerf_pack_mlp', W, B, self.n_linear, self.d_filter, self.d_out, precision, _ptr(buffer),
                 _stream(self.device))
 
-    def probe(self, rays_o, rays_d, times, z_vals, reg_radius: float) -> float:
-        """AUTO: renders the first PROBE_RAYS rays in both arithmetics, keeps FAST if it is inside the gate with margin,
+    def probe(self, rays_o, rays_d, times, z_vals, reg_radius: float, sensitivity: float = 1.0) -> float:
+        """AUTO: renders PROBE_RAYS rays of the call in both arithmetics, keeps FAST if it is inside the gate with margin,
         switches this image to EXACT otherwise (and back when a later probe allows it).  One 4-byte device -> host read
-        per PROBE_EVERY parameter versions.  Returns the measured gate units."""
-        n = min(PROBE_RAYS, rays_o.shape[0])
+        per PROBE_EVERY parameter versions.  Returns the measured gate units.  ``sensitivity``: how much more strongly than
+        the emission image the caller's own integral reacts to an error of the raw output (the density-temperature image goes
+        with exp(2 raw_0): 2) -- the measured units are multiplied by it."""
+        total = rays_o.shape[0]
+        n = min(PROBE_RAYS, total)
         self.probe_due = False
         self._versions_since_probe = 0
         if n == 0:
             return 0.0
+        # PROBE_RAYS rays spread evenly over the call (the first rays of a frame are an off-disk corner of the image)
+        sel = slice(0, (total // n) * n, total // n)
+        rays_o, rays_d, z_vals = rays_o[sel].contiguous(), rays_d[sel].contiguous(), z_vals[sel].contiguous()
+        times = times.reshape(-1)[sel].contiguous()
         if getattr(self, '_alt_buffer', None) is None:
             self._alt_buffer = torch.empty_like(self.buffer)
         other = PRECISION_EXACT if self.precision == PRECISION_FAST else PRECISION_FAST
@@ -172,15 +179,14 @@ class PackedMLP:
             shadow = object.__new__(PackedMLP)
             shadow.__dict__.update(self.__dict__)
             shadow.buffer, shadow.precision, shadow.auto = buf, mode, False
-            outs[mode] = emission_render_fwd(shadow, rays_o[:n], rays_d[:n], times.reshape(-1)[:n], z_vals[:n], reg_radius,
-                                             want_epilogues=True)
+            outs[mode] = emission_render_fwd(shadow, rays_o, rays_d, times, z_vals, reg_radius, want_epilogues=True)
         units = torch.zeros((), dtype=torch.float32, device=self.device)
         for k in ('image', 'height_map', 'absorption_map'):
             f, e = outs[PRECISION_FAST][k].reshape(-1), outs[PRECISION_EXACT][k].reshape(-1)
             # absorption_map = sum(1 - a): the reference forms 1 - a in fp32, i.e. with 2^-24 absolute noise per sample
             floor = z_vals.shape[1] * 6e-8 if k == 'absorption_map' else 0.0
             units = torch.maximum(units, ((f - e).abs() / (1e-4 * e.abs() + 1e-6 * e.abs().max() + floor)).max())
-        units = float(units.item())
+        units = float(units.item()) * float(sensitivity)
         if not (units == units):            # NaN: non-finite outputs in either mode -- leave the decision to the finite check
             units = float('inf')
         self.last_probe = units
@@ -222,7 +228,8 @@ def sample_z(kind: int, rays_o, rays_d, t_vals, distance: float, solar_R: float,
 
 
 def emission_render_fwd(packed: PackedMLP, rays_o, rays_d, times, z_vals, reg_radius: float,
-                        want_raw: bool = False, want_epilogues: bool = False, training: bool = False):
+                        want_raw: bool = False, want_epilogues: bool = False, training: bool = False,
+                        probe_sensitivity: float = 1.0):
     """One fused render pass.  Returns dict(image (N,1), weights (N,S), absorption (N,S)[, raw (N,S,2)]
     [, height_map (N,), absorption_map (N,), regularization (N,S)][, stash]).  ``training=True`` also writes the
     activation stash needed by :func:`emission_render_bwd` (and implies ``want_raw``)."""
@@ -236,7 +243,7 @@ def emission_render_fwd(packed: PackedMLP, rays_o, rays_d, times, z_vals, reg_ra
     if packed.device != dev:
         raise _l.SunerfHipError('packed weights and rays are on different devices')
     if packed.auto and packed.probe_due:
-        packed.probe(rays_o, rays_d, times, z_vals, reg_radius)
+        packed.probe(rays_o, rays_d, times, z_vals, reg_radius, probe_sensitivity)
     f32 = dict(dtype=torch.float32, device=dev)
     out = {'image': torch.empty(n, 1, **f32), 'weights': torch.empty(n, s, **f32),
            'absorption': torch.empty(n, s, **f32)}
