@@ -637,6 +637,7 @@ static int launch_dgrad(const DgradArgs& a, hipStream_t stream) {
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  cus = sunerf_grid_cap("SUNERF_GRID_CAP_DGRAD", cus);
   const unsigned grid = (unsigned)(n_groups < cus ? n_groups : cus);
   const size_t lds = (size_t)sunerf_ring::Ring<D>::RING;
   hipError_t e = hipFuncSetAttribute((const void*)dgrad_pair_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

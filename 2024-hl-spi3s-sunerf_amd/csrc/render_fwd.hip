@@ -1221,6 +1221,7 @@ int launch_render_t(const RenderArgs& a, hipStream_t stream) {
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (cus > 1024) cus = 1024;   // sunerf_render_workspace_bytes is sized for at most 1024 workgroups
+  cus = sunerf_grid_cap("SUNERF_GRID_CAP_FWD", cus);
   const unsigned grid = (unsigned)(n_groups < cus ? n_groups : cus);
   SUNERF_CLEAR_ERROR();
   hipLaunchKernelGGL((render_fwd_kernel<D, STASH, FP8C, HALF>), dim3(grid), dim3(THREADS), lds, stream, a);

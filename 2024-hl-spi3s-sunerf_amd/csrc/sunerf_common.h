@@ -39,6 +39,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #define SUNERF_KS0 6  // k-steps of the in layer (96 = 84 padded)
 
@@ -114,6 +115,13 @@ __host__ __device__ inline int acc_row(int g, int h) { return (g & 3) + 8 * (g >
 
 // hipGetLastError() reports the last error of ANY earlier runtime call on this thread (e.g. a probe made by the
 // caller's framework): clear it before a launch so that the check after the launch sees only our own.
+// Experiment knob (tools/experiments/overlap_probe.py): SUNERF_GRID_CAP_FWD / _DGRAD limit a persistent kernel's grid
+// below the CU count so that two kernels can run side by side on disjoint CUs.  Read at every launch; unset = all CUs.
+static inline int sunerf_grid_cap(const char* name, int cus) {
+  const char* s = getenv(name);
+  const int v = s ? atoi(s) : 0;
+  return (v > 0 && v < cus) ? v : cus;
+}
 #define SUNERF_CLEAR_ERROR() (void)hipGetLastError()
 #define SUNERF_CHECK_LAUNCH()                         \
   do {                                                \

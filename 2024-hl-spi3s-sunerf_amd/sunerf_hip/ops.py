@@ -4,6 +4,7 @@ PyTorch is used for device memory and streams only; every numerical op of the re
 kernels of ``csrc/``.
 """
 import ctypes
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -369,7 +370,9 @@ def mlp_backward(packed: PackedMLP, g_raw, absmax, stash, grad_weights: Sequence
     dz = torch.empty(lib.sunerf_dz_stash_bytes(n, s, D, nl), dtype=torch.uint8, device=dev)
     _l.call(dev, 'sunerf_mlp_dgrad', _ptr(packed.transposed()), D, nl, _ptr(g_raw), _ptr(absmax), _ptr(stash),
             _ptr(dz), n, s, stream)
-    split = wgrad_split(nl, torch.cuda.get_device_properties(dev).multi_processor_count, D)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    cap = int(os.environ.get('SUNERF_GRID_CAP_WGRAD', 0))        # experiment knob, see csrc/sunerf_common.h
+    split = wgrad_split(nl, cap if 0 < cap < cus else cus, D)
     ws = torch.empty(lib.sunerf_wgrad_workspace_bytes(packed.d_filter, nl, split), dtype=torch.uint8, device=dev)
     out_w, out_b = list(grad_weights), list(grad_biases)
     if packed.padded:
