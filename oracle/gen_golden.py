@@ -27,6 +27,10 @@ Fixtures:
                     sunerf.py:30-40 with lr_config start 1e-3, clip_grad_norm_ 0.5 as run_emission.py:72, loss
                     sunerf.py:110-120) on a limb-brightened synthetic target, then rendered: weights away from their
                     initialisation (the fp8-correction arithmetic had only been proven on fresh nn.Linear inits)
+  g12_half_emulated SURVEY G8 ("emulated low-precision variants of G2 / G5"): NOT reference output -- the reference has no
+                    low-precision path.  The oracle's emulation of the opt-in HALF arithmetic (fp16 operands of every
+                    product, exact sums: oracle/sunerf_oracle.py mlp_forward_half) applied to the reference weights and inputs
+                    of the committed g2 and g5b fixtures, with its deviation from the reference's fp32 outputs recorded.
 """
 import os
 import sys
@@ -227,6 +231,7 @@ def main():
     gen_g9(ref)
     gen_g10(ref)
     gen_g11(ref)
+    gen_g12(ref)
     ref_import.release_reference()
 
 
@@ -439,6 +444,27 @@ def gen_g11(ref):
     npz('g11_trained', **arrays)
 
 
+def gen_g12(_ref=None):
+    """Emulated-HALF variants of g2 (network outputs) and g5b (coarse render pass).  Needs no reference import: inputs and
+    weights are read from the COMMITTED g2 / g5b files (reference data), outputs come from the oracle's emulation."""
+    def load(name):
+        with np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False) as f:
+            return {k: torch.from_numpy(f[k]) for k in f.files}
+
+    def params(g, prefix):
+        return orc.params_from_state_dict({k[len(prefix):].replace('__', '.'): v for k, v in g.items() if k.startswith(prefix)}, '')
+    torch.set_num_threads(1)
+    g2, g5b = load('g2_mlp'), load('g5b_emission_d256')
+    inf16 = orc.mlp_forward_half(params(g2, 'net__'), g2['x'])
+    z = g5b['out__z_vals_stratified']
+    p16 = orc.render_pass(params(g5b, 'sd__coarse_model__'), g5b['rays_o'], g5b['rays_d'], g5b['times'], z, half=True)
+    dev = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()   # noqa: E731
+    npz('g12_half_emulated', g2__inferences_half=inf16, g2__deviation_from_fp32=dev(inf16, g2['inferences']),
+        g5b__raw_half=p16['raw'], g5b__image_half=p16['image'], g5b__weights_half=p16['weights'],
+        g5b__absorption_half=p16['regularizing_quantity'],
+        g5b__image_deviation_from_fp32=dev(p16['image'], g5b['out__coarse_image']))
+
+
 def compare_with_committed(out_dir):
     """Bit-compares every array of every fixture in ``out_dir`` with the committed file of the same name.
     Returns a list of human-readable differences (empty = the script reproduces the committed fixtures)."""
@@ -471,7 +497,7 @@ def generate(out_dir=None, only=None):
             torch.set_num_threads(1)
             ref = ref_import.import_reference()
             for a in only:
-                {'g7': gen_g7, 'g8': gen_g8, 'g9': gen_g9, 'g10': gen_g10, 'g11': gen_g11}[a](ref)
+                {'g7': gen_g7, 'g8': gen_g8, 'g9': gen_g9, 'g10': gen_g10, 'g11': gen_g11, 'g12': gen_g12}[a](ref)
             ref_import.release_reference()
         else:
             main()
@@ -485,10 +511,10 @@ if __name__ == '__main__':
     ap.add_argument('--out', default=None, help='write the fixtures here instead of tests/golden')
     ap.add_argument('--check', action='store_true',
                     help='regenerate into a scratch directory and bit-compare with the committed fixtures')
-    ap.add_argument('only', nargs='*', help='regenerate only these (g7 g8 g9 g10 g11)')
+    ap.add_argument('only', nargs='*', help='regenerate only these (g7 g8 g9 g10 g11 g12)')
     args = ap.parse_args()
-    if any(a not in ('g7', 'g8', 'g9', 'g10', 'g11') for a in args.only):
-        ap.error('only g7 g8 g9 g10 g11 can be regenerated on their own')
+    if any(a not in ('g7', 'g8', 'g9', 'g10', 'g11', 'g12') for a in args.only):
+        ap.error('only g7 g8 g9 g10 g11 g12 can be regenerated on their own')
     if args.check:
         import tempfile
         with tempfile.TemporaryDirectory() as tmp:

@@ -154,3 +154,24 @@ def test_half_precision_follows_emulated_oracle(ops, d_filter, n_layers, monkeyp
     dev32 = rel_err(out['image'], ref32['image'])
     print(f'HALF d={d_filter} L={n_layers}: image deviation from the fp32 evaluation {dev32:.2e}')
     assert 1e-6 < dev32 < 2e-2
+
+
+def test_half_precision_against_the_committed_emulated_fixture(ops):
+    """SURVEY G8 (fixture g12): HALF mode on the reference weights / inputs of g2 and g5b against the committed outputs of the
+    emulating oracle, at 1e-4 of the tensor's scale (a flipped fp16 rounding of one hidden value moves raw by ~4e-5)."""
+    g12, g2, g5b = load_golden('g12_half_emulated'), load_golden('g2_mlp'), load_golden('g5b_emission_d256')
+    params = params_from_golden(g2, 'net__')
+    packed = ops.PackedMLP([dev(W) for W, _ in params], [dev(b) for _, b in params], precision=ops.PRECISION_HALF)
+    x = g2['x']
+    out = ops.emission_render_fwd(packed, dev(torch.zeros(x.shape[0], 3)), dev(x[:, :3].contiguous()), dev(x[:, 3:].contiguous()),
+                                  dev(torch.ones(x.shape[0], 2)), reg_radius=1.2, want_raw=True)
+    assert rel_err(out['raw'][:, 0], g12['g2__inferences_half']) < 1e-4
+    params = params_from_golden(g5b, 'sd__coarse_model__')
+    packed = ops.PackedMLP([dev(W) for W, _ in params], [dev(b) for _, b in params], precision=ops.PRECISION_HALF)
+    out = ops.emission_render_fwd(packed, dev(g5b['rays_o']), dev(g5b['rays_d']), dev(g5b['times']),
+                                  dev(g5b['out__z_vals_stratified']), reg_radius=1.2, want_raw=True)
+    torch.cuda.synchronize()
+    assert (out['raw'].cpu() - g12['g5b__raw_half']).abs().max().item() < 2e-4
+    assert rel_err(out['image'], g12['g5b__image_half']) < 1e-4
+    assert rel_err(out['weights'], g12['g5b__weights_half']) < 1e-4
+    assert rel_err(out['absorption'], g12['g5b__absorption_half']) < 1e-4

@@ -48,6 +48,20 @@ def test_g2_encoding_and_mlp_bit_exact():
     exact(orc.mlp_forward(params, g['x']), g['inferences'])
 
 
+def test_g12_emulated_half_arithmetic_is_pinned():
+    """the oracle's emulation of the opt-in HALF arithmetic on the reference weights of g2 / g5b.  Not reference
+    output (the reference has no low-precision path); the fixture pins the emulation the GPU HALF mode is held to and
+    records how far that arithmetic is from the reference's fp32 results (6e-4 / 4e-4: outside the 1e-4 gate, opt-in)."""
+    g12, g2, g5b = load_golden('g12_half_emulated'), load_golden('g2_mlp'), load_golden('g5b_emission_d256')
+    exact(orc.mlp_forward_half(params_from_golden(g2, 'net__'), g2['x']), g12['g2__inferences_half'])
+    p = orc.render_pass(params_from_golden(g5b, 'sd__coarse_model__'), g5b['rays_o'], g5b['rays_d'], g5b['times'],
+                        g5b['out__z_vals_stratified'], half=True)
+    exact(p['raw'], g12['g5b__raw_half'])
+    exact(p['image'], g12['g5b__image_half'])
+    assert 1e-4 < g12['g2__deviation_from_fp32'].item() < 2e-3
+    assert 1e-4 < g12['g5b__image_deviation_from_fp32'].item() < 2e-3
+
+
 def test_g3_emission_integral_and_grad():
     g = load_golden('g3_integral')
     raw = g['raw'].clone().requires_grad_(True)
