@@ -66,13 +66,49 @@ def linear_plate_scale_axes(grid: dict, resolution=None, device='cuda') -> Tuple
     return ((col - cpx) * cdx + cvx) * ARCSEC, ((row - cpy) * cdy + cvy) * ARCSEC
 
 
+def load_state_file(state_path):
+    """``torch.load`` of a ``.snf`` state (sunerf.py:62-74).  A density-temperature state written by the reference holds
+    ``xitorch.interpolate.Interp1D`` objects (density_temperature.py:143-146); where xitorch is not installed a state-only
+    stand-in of that name is registered for the load, and ``DensityTemperatureRadiativeTransfer.__setstate__`` takes the
+    response table out of whatever the objects carry."""
+    try:
+        return torch.load(state_path, map_location='cpu', weights_only=False)
+    except ModuleNotFoundError as err:
+        if err.name not in ('xitorch', 'xitorch.interpolate'):
+            raise
+    import sys
+    import types
+
+    class _Anything:                      # every class the pickle names under xitorch.* becomes a plain state holder
+        def __init__(self, *a, **k):
+            pass
+
+    class _StandIn(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith('__'):
+                raise AttributeError(name)
+            cls = type(name, (_Anything,), {'__module__': self.__name__})
+            setattr(self, name, cls)
+            return cls
+    added = {}
+    try:
+        for name in ('xitorch', 'xitorch.interpolate', 'xitorch.interpolate.interp1', 'xitorch.interpolate.base_interp',
+                     'xitorch._core', 'xitorch._core.editable_module'):
+            if name not in sys.modules:
+                added[name] = sys.modules[name] = _StandIn(name)
+        return torch.load(state_path, map_location='cpu', weights_only=False)
+    finally:
+        for name in added:
+            sys.modules.pop(name, None)
+
+
 class SuNeRFLoader:
     """loader.py:16-134."""
 
     def __init__(self, state_path, device=None):
         device = torch.device('cuda') if device is None else torch.device(device)
         self.device = device
-        state = torch.load(state_path, map_location='cpu', weights_only=False)
+        state = load_state_file(state_path)
         data_config = state['data_config']
         self.config = data_config
         self.wavelength = data_config.get('wavelength')

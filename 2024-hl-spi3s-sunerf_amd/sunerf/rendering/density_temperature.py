@@ -4,7 +4,40 @@ import torch
 from sunerf.model.model import NeRF_DT
 from sunerf.rendering.base_tracing import SuNeRFRendering
 from sunerf.rendering.functional import dt_pass, dt_raw2outputs
-from sunerf_hip.genx import read_aia_temp_resp
+from sunerf_hip.genx import CHANNELS, read_aia_temp_resp
+
+
+def _tensors_inside(obj, depth=3):
+    """1-D tensors reachable through the attributes of ``obj`` (an interpolator object of unknown class)."""
+    found = []
+    if torch.is_tensor(obj):
+        return [obj] if obj.ndim == 1 and obj.numel() >= 2 else []
+    if depth == 0:
+        return found
+    for v in (vars(obj).values() if hasattr(obj, '__dict__') else (obj if isinstance(obj, (list, tuple)) else ())):
+        found += _tensors_inside(v, depth - 1)
+    return found
+
+
+def _tables_from_interpolators(response):
+    """(logte [7, n], response [7, n]) out of the ``{wavelength: Interp1D(logte, tresp * exposure)}`` dict a reference-written
+    state carries (density_temperature.py:132-146): per channel the strictly increasing grid and the other tensor of its
+    length.  None when the objects do not show them (then the table is read from the file again)."""
+    rows_x, rows_y = [], []
+    for channel in CHANNELS:
+        ts = _tensors_inside(response.get(channel))
+        grids = [t for t in ts if bool((t[1:] > t[:-1]).all())]
+        if not grids:
+            return None
+        x = grids[0]
+        ys = [t for t in ts if t is not x and t.numel() == x.numel() and t.data_ptr() != x.data_ptr()]
+        if len(ys) != 1:
+            return None
+        rows_x.append(x.detach().float().cpu())
+        rows_y.append(ys[0].detach().float().cpu())
+    if len({r.numel() for r in rows_x}) != 1:
+        return None
+    return torch.stack(rows_x), torch.stack(rows_y)
 
 
 class DensityTemperatureRadiativeTransfer(SuNeRFRendering):
@@ -24,6 +57,35 @@ class DensityTemperatureRadiativeTransfer(SuNeRFRendering):
         # density_temperature.py:137-146: response x exposure time, cast to fp32
         self.register_buffer('response_logte', torch.as_tensor(logte).float(), persistent=False)
         self.register_buffer('response_table', torch.as_tensor(tresp * aia_exp_time).float(), persistent=False)
+
+    # ---- .snf compatibility in both directions (sunerf.py:62-74 pickles this object) ---------------------------------
+    def __getstate__(self):
+        """What the reference's class needs besides modules and scalars is ``self.response`` (density_temperature.py:132-146,
+        read at :248): one ``xitorch`` interpolator per channel.  Where xitorch is installed -- any environment that runs the
+        reference -- they are built through its public constructor exactly as the reference builds them, so that a state
+        written here renders in the reference; elsewhere the file simply lacks them (and still loads here)."""
+        st = self.__dict__.copy()
+        try:
+            from xitorch.interpolate import Interp1D
+        except ImportError:
+            return st
+        x, y = self._buffers['response_logte'], self._buffers['response_table']
+        st['response'] = {c: Interp1D(x[i].clone(), y[i].clone(), method='linear', extrap=0) for i, c in enumerate(CHANNELS)}
+        return st
+
+    def __setstate__(self, state):
+        """A state written by the REFERENCE has the interpolators but not this class's table buffers: take the table out of
+        them, or read the file again like the constructor."""
+        self.__dict__.update(state)
+        if 'response_logte' in self._buffers and 'response_table' in self._buffers:
+            return
+        tables = _tables_from_interpolators(state['response']) if isinstance(state.get('response'), dict) else None
+        if tables is None:
+            logte, tresp = read_aia_temp_resp("sunerf/data/aia_temp_resp.genx")
+            tables = torch.as_tensor(logte).float(), torch.as_tensor(tresp * 2.9).float()     # the constructor's default exposure
+        where = next((p.device for p in self.parameters()), torch.device('cpu'))
+        self.register_buffer('response_logte', tables[0].to(where), persistent=False)
+        self.register_buffer('response_table', tables[1].to(where), persistent=False)
 
     def regularization(self, distance, regularizing_quantity):
         return torch.relu(distance[:, :] - 1.25 / self.Rs_per_ds) * torch.relu(regularizing_quantity)

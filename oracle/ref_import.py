@@ -62,6 +62,31 @@ class _Quantity:
         return self.base / (unit.base if isinstance(unit, _Quantity) else unit.scale)
 
 
+class Interp1D:
+    """Stand-in for ``xitorch.interpolate.Interp1D`` (not installed): the documented semantics of the one form the reference
+    uses -- ``method='linear', extrap=0`` -- restated.  Module level and registered under xitorch's module path so that state
+    files holding such objects (density_temperature.py:143-146 puts them into the pickled rendering module) can be written
+    and read in the container the way a real installation writes and reads them."""
+
+    def __init__(self, x, y, method='linear', extrap=0):
+        assert method == 'linear' and extrap == 0
+        self.x, self.y = x, y
+
+    def __call__(self, xq):
+        import sunerf_oracle as orc
+        return orc.interp1d_linear_extrap0(self.x, self.y, xq)
+
+
+Interp1D.__module__ = 'xitorch.interpolate'
+
+
+def install_xitorch_stub():
+    if 'xitorch' not in sys.modules:
+        for name in ('xitorch', 'xitorch.interpolate'):
+            sys.modules[name] = types.ModuleType(name)
+        sys.modules['xitorch.interpolate'].Interp1D = Interp1D
+
+
 def _install_stubs():
     if 'astropy' not in sys.modules:
         astropy = types.ModuleType('astropy')
@@ -90,18 +115,10 @@ def _install_stubs():
                 out[f'A{w}'] = {'LOGTE': logte[c], 'TRESP': tresp[c]}
             return out
 
-        class Interp1D:
-            def __init__(self, x, y, method='linear', extrap=0):
-                assert method == 'linear' and extrap == 0
-                self.x, self.y = x, y
-
-            def __call__(self, xq):
-                return orc.interp1d_linear_extrap0(self.x, self.y, xq)
-
-        for name in ('sunpy', 'sunpy.io', 'sunpy.io.special', 'xitorch', 'xitorch.interpolate'):
+        for name in ('sunpy', 'sunpy.io', 'sunpy.io.special'):
             sys.modules[name] = types.ModuleType(name)
         sys.modules['sunpy.io.special'].read_genx = read_genx
-        sys.modules['xitorch.interpolate'].Interp1D = Interp1D
+        install_xitorch_stub()
 
 
 def import_reference():
