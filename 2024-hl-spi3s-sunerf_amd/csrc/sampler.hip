@@ -62,6 +62,9 @@ constexpr int RS_RAYS = RS_THREADS / RS_G;      // rays per workgroup
 // the merge -- as rank computations: position of z_i = i + #{new < z_i}, position of new_j = j + #{z <= new_j}, the order a
 // stable two-run merge produces -- are dealt out over the 8 lanes.  Lanes of a group sit in one wave, LDS operations of a
 // wave complete in order, so no barrier separates the phases.
+// BINS_GIVEN (HierarchicalSampler.sample_pdf called by itself, sampling.py:128-169): `z_vals` holds the nb = Sc - 1 bin
+// positions of every ray and `weights` their nb - 1 weights as they are (no mid points, no [1:-1] slice, no merge).
+template <bool BINS_GIVEN>
 __global__ __launch_bounds__(RS_THREADS) void hier_resample_kernel(
     const float* __restrict__ z_vals, const float* __restrict__ weights, const float* __restrict__ u_in,
     int u_per_ray, int64_t n_rays, int Sc, int Sf, float* __restrict__ new_z_out, float* __restrict__ z_comb) {
@@ -75,9 +78,10 @@ __global__ __launch_bounds__(RS_THREADS) void hier_resample_kernel(
   float* bins = cdf + nb;                // [nb]
   float* nz = bins + nb;                 // [Sf] new samples
   float* zc = nz + Sf;                   // [Sc] coarse samples
-  const float* z = z_vals + ray * Sc;
-  const float* w = weights + ray * Sc;
-  for (int i = g; i < Sc; i += RS_G) zc[i] = z[i];
+  const float* z = z_vals + ray * (BINS_GIVEN ? nb : Sc);
+  const float* w = BINS_GIVEN ? weights + ray * (nb - 1) - 1 : weights + ray * Sc;   // w[1 .. Sc-2] are the pdf's entries
+  if (!BINS_GIVEN)
+    for (int i = g; i < Sc; i += RS_G) zc[i] = z[i];
   bool z_sorted = true;
   if (g == 0) {
     // pdf = (w[1:-1] + 1e-5) / sum(w[1:-1] + 1e-5)      (Sc-2 entries)
@@ -95,9 +99,13 @@ __global__ __launch_bounds__(RS_THREADS) void hier_resample_kernel(
     }
   }
   for (int i = g; i < nb; i += RS_G) {
-    const float z0 = z[i], z1 = z[i + 1];
-    bins[i] = .5f * (z1 + z0);
-    z_sorted = z_sorted && (z1 >= z0);
+    if (BINS_GIVEN) {
+      bins[i] = z[i];
+    } else {
+      const float z0 = z[i], z1 = z[i + 1];
+      bins[i] = .5f * (z1 + z0);
+      z_sorted = z_sorted && (z1 >= z0);
+    }
   }
   __builtin_amdgcn_wave_barrier();
   // inverse CDF: sample j of this lane
@@ -119,6 +127,7 @@ __global__ __launch_bounds__(RS_THREADS) void hier_resample_kernel(
     if (ray_ok) new_z_out[ray * Sf + j] = sv;
     nz[j] = sv;
   }
+  if (BINS_GIVEN) return;
   __builtin_amdgcn_wave_barrier();
   bool sorted = z_sorted;
   for (int j = g; j < Sf; j += RS_G)
@@ -192,12 +201,33 @@ extern "C" int sunerf_hier_resample(const float* z_vals, const float* weights, c
   const int64_t blocks = (n_rays + RS_RAYS - 1) / RS_RAYS;
   if (blocks > 0x7fffffffLL) return SUNERF_E_UNSUPPORTED;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)hier_resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)hier_resample_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   SUNERF_CLEAR_ERROR();
-  hipLaunchKernelGGL(hier_resample_kernel, dim3((unsigned)blocks), dim3(RS_THREADS), lds, (hipStream_t)stream, z_vals,
+  hipLaunchKernelGGL(hier_resample_kernel<false>, dim3((unsigned)blocks), dim3(RS_THREADS), lds, (hipStream_t)stream, z_vals,
                      weights, u, u_per_ray, n_rays, n_coarse, n_fine, new_z, z_comb);
+  SUNERF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sunerf_sample_pdf(const float* bins, const float* weights, const float* u, int u_per_ray, int64_t n_rays,
+                                 int n_bins, int n_fine, float* samples, void* stream) {
+  if (n_rays < 0 || n_bins < 2 || n_fine < 1) return SUNERF_E_BADARG;
+  if (n_rays == 0) return 0;
+  if (!bins || !weights || !u || !samples) return SUNERF_E_BADARG;
+  const int sc = n_bins + 1;             // the kernel's LDS layout is that of n_bins + 1 coarse samples
+  const size_t lds = ((size_t)2 * n_bins + n_fine + sc) * RS_RAYS * sizeof(float);
+  if (lds > 160 * 1024) return SUNERF_E_UNSUPPORTED;
+  const int64_t blocks = (n_rays + RS_RAYS - 1) / RS_RAYS;
+  if (blocks > 0x7fffffffLL) return SUNERF_E_UNSUPPORTED;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)hier_resample_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  SUNERF_CLEAR_ERROR();
+  hipLaunchKernelGGL(hier_resample_kernel<true>, dim3((unsigned)blocks), dim3(RS_THREADS), lds, (hipStream_t)stream, bins,
+                     weights, u, u_per_ray, n_rays, sc, n_fine, samples, (float*)nullptr);
   SUNERF_CHECK_LAUNCH();
   return 0;
 }

@@ -17,6 +17,10 @@ class Sine(nn.Module):
         super().__init__()
         self.w0 = w0
 
+    def forward(self, x):
+        """Stand-alone use of the activation (model.py:71-72); inside ``NeRF`` it is part of the fused kernels."""
+        return torch.sin(x * self.w0)
+
 
 class PositionalEncoding(nn.Module):
     """model.py:92-132: [x, sin(x f_k / 2), cos(x f_k / 2)], f_k = 2^k, k = 0..n_freqs-1 (fused into the kernel)."""
@@ -32,6 +36,30 @@ class PositionalEncoding(nn.Module):
         self.d_output = d_input * (1 + 2 * n_freqs)
         self.register_buffer('freq_bands', 2. ** torch.linspace(0., n_freqs - 1, n_freqs))
         self.scale_factor = scale_factor
+
+    def forward(self, x) -> torch.Tensor:
+        """Stand-alone use of the encoder (model.py:123-132): (M, d) -> (M, d (1 + 2 n_freqs)) = [x, sin block, cos block],
+        each block frequency-major.  Inside ``NeRF`` the encoding is computed in the fused kernels; this is for callers that
+        apply the module by itself (element-wise torch on the tensor's own device)."""
+        phase = (x.unsqueeze(1) * self.freq_bands.view(1, -1, 1) / self.scale_factor).flatten(1)
+        return torch.cat((x, phase.sin(), phase.cos()), dim=-1)
+
+
+class TrainablePositionalEncoding(nn.Module):
+    """model.py:75-89 (constructed nowhere in the reference; kept so that ``from sunerf.model.model import *`` code finds it):
+    ``d_input`` x ``n_freqs`` learnable exponents f, output [sin(pi 2^f x), cos(pi 2^f x)] / (pi 2^f), (M, 2 n_freqs d_input).
+    Not connected to the fused kernels."""
+
+    def __init__(self, d_input, n_freqs=20):
+        super().__init__()
+        exponents = torch.linspace(-3, 9, n_freqs, dtype=torch.float32).view(1, n_freqs, 1).repeat(1, 1, d_input)
+        self.frequencies = nn.Parameter(exponents, requires_grad=True)
+        self.d_output = n_freqs * 2 * d_input
+
+    def forward(self, x):
+        scale = torch.pi * torch.pow(2., self.frequencies)          # (1, n_freqs, d)
+        phase = x.unsqueeze(1) * scale
+        return torch.cat((phase.sin() / scale, phase.cos() / scale), dim=-1).flatten(1)
 
 
 class NeRF(nn.Module):
@@ -90,6 +118,13 @@ class NeRF(nn.Module):
         """(M, 4) query points -> {'inferences': (M, d_output)} (model.py:44-57)."""
         from sunerf.rendering.functional import mlp_points
         return {'inferences': mlp_points(self, x)}
+
+
+class EmissionModel(NeRF):
+    """model.py:60-63: ``NeRF`` with ``d_input = 4``, ``d_output = 2`` fixed."""
+
+    def __init__(self, **kwargs):
+        super().__init__(d_input=4, d_output=2, **kwargs)
 
 
 class NeRF_DT(NeRF):

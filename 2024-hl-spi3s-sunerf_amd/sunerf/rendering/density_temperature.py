@@ -2,7 +2,7 @@
 import torch
 
 from sunerf.model.model import NeRF_DT
-from sunerf.rendering.base_tracing import SuNeRFRendering
+from sunerf.rendering.base_tracing import SuNeRFRendering, field_on_query_points
 from sunerf.rendering.functional import dt_pass, dt_raw2outputs
 from sunerf_hip.genx import CHANNELS, read_aia_temp_resp
 
@@ -94,6 +94,8 @@ class DensityTemperatureRadiativeTransfer(SuNeRFRendering):
         """base_tracing.py:46-111 for the DT subclass: same 8 output keys, images are (N, W)."""
         if wavelengths is None:
             raise ValueError('DensityTemperatureRadiativeTransfer needs the wavelengths of every ray')
+        if self._hooks_replaced(DensityTemperatureRadiativeTransfer):   # a subclass with its own raw2outputs / _render / regularization
+            return SuNeRFRendering.forward(self, rays_o, rays_d, times, wavelengths)
         tables = (self.response_logte, self.response_table)
         reg_radius = 1.25 / self.Rs_per_ds
         z_vals = self.sampler.z_vals(rays_o, rays_d)
@@ -105,6 +107,12 @@ class DensityTemperatureRadiativeTransfer(SuNeRFRendering):
         return {'z_vals_stratified': z_vals, 'coarse_image': coarse['image'], 'z_vals_hierarchical': new_z,
                 'fine_image': fine['image'], 'image': fine['image'], 'height_map': fine['height_map'],
                 'absorption_map': fine['absorption_map'], 'regularization': fine['regularization']}
+
+    def _render(self, model, query_points, rays_d, rays_o, z_vals, wavelengths):
+        """density_temperature.py:148-190: ``model.forward`` at the query points -- inferences with the base offsets, the
+        absorption scalars, the volumetric constant -- plus ``z_vals`` / ``rays_d`` / ``wavelengths`` into ``raw2outputs``."""
+        inferences, state = field_on_query_points(model, query_points, rays_o, rays_d, z_vals)
+        return self.raw2outputs(inferences=inferences, z_vals=z_vals, rays_d=rays_d, wavelengths=wavelengths, **state)
 
     def raw2outputs(self, inferences, log_abs, vol_c, z_vals, rays_d, wavelengths, **kwargs):
         """density_temperature.py:192-271 on the state ``NeRF_DT.forward`` returns (``inferences`` (N, S, 2) with the base

@@ -14,6 +14,8 @@ class EmissionRadiativeTransfer(SuNeRFRendering):
 
     def forward(self, rays_o, rays_d, times, wavelengths=None):
         """base_tracing.py:46-111 for the emission subclass: same 8 output keys."""
+        if self._hooks_replaced(EmissionRadiativeTransfer):      # a subclass with its own raw2outputs / _render / regularization
+            return SuNeRFRendering.forward(self, rays_o, rays_d, times, wavelengths)
         if wavelengths is not None:
             raise ValueError('EmissionRadiativeTransfer takes no wavelengths')
         z_vals = self.sampler.z_vals(rays_o, rays_d)

@@ -112,6 +112,60 @@ def emission_pass(model, rays_o, rays_d, times, z_vals, reg_radius, want_epilogu
                                    want_epilogues=want_epilogues)
 
 
+class _MlpOnRays(torch.autograd.Function):
+    """``NeRF.forward`` (model.py:44-57) on the samples ``o + d z`` of a ray batch as an autograd node: the raw network output
+    (N, S, d_output), differentiable w.r.t. the model's parameters.  This is what the generic ``SuNeRFRendering._render``
+    (base_tracing.py:118-129) hands to a subclass's ``raw2outputs``: the MLP runs in the fused render kernel (whose own
+    integral outputs are ignored) and its backward in the data / weight gradient kernels, fed with whatever gradient the
+    subclass's torch code sends back."""
+
+    @staticmethod
+    def forward(ctx, model, rays_o, rays_d, times, z_vals, *params):
+        training = any(ctx.needs_input_grad[5:])
+        packed = model.packed()
+        out = ops.emission_render_fwd(packed, rays_o, rays_d, times, z_vals, 0.0, want_raw=True, training=training)
+        ctx.training = training
+        if training:
+            ctx.packed, ctx.params = packed, params
+            ctx.param_meta = [(p.shape, p.device) for p in params]
+            ctx.save_for_backward(out['stash'])
+        ctx.d_out = packed.d_out
+        return out['raw'][..., :packed.d_out] if packed.d_out < 2 else out['raw']
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        stash, = ctx.saved_tensors
+        if g_raw.shape[-1] < 2:
+            g_raw = torch.cat([g_raw, torch.zeros_like(g_raw)], -1)
+        g_raw = g_raw.contiguous().float()
+        # bit pattern of max |g_raw|: the scale the fp16 backward arithmetic is normalised with (sunerf_common.h)
+        absmax = g_raw.abs().max().reshape(1).view(torch.int32)
+        direct = _grad_targets(ctx.params)
+        if direct is not None:
+            ops.mlp_backward(ctx.packed, g_raw, absmax, stash, direct[0], direct[1], accumulate=True)
+            _announce(ctx.params)
+            return (None,) * (5 + len(ctx.params))
+        gW = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[0::2]]
+        gb = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[1::2]]
+        ops.mlp_backward(ctx.packed, g_raw, absmax, stash, gW, gb)
+        grads = []
+        for w, b in zip(gW, gb):
+            grads += [w, b]
+        return (None,) * 5 + tuple(grads)
+
+
+def mlp_on_rays(model, rays_o, rays_d, times, z_vals) -> torch.Tensor:
+    """(N, S, d_output) raw output of ``model`` (a ``NeRF``) at the samples of the rays; goes through autograd when the
+    model is trainable and gradients are enabled."""
+    params = []
+    for lin in model.linears():
+        params += [lin.weight, lin.bias]
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        return _MlpOnRays.apply(model, rays_o, rays_d, times, z_vals, *params)
+    raw = ops.emission_render_fwd(model.packed(), rays_o, rays_d, times, z_vals, 0.0, want_raw=True)['raw']
+    return raw[..., :model.packed().d_out] if model.packed().d_out < 2 else raw
+
+
 class _EmissionIntegral(torch.autograd.Function):
     """``EmissionRadiativeTransfer.raw2outputs`` (emission.py:14-54) on a given raw tensor: differentiable w.r.t. ``raw`` through
     all three outputs (image, weights, regularizing_quantity), like the reference's autograd graph."""

@@ -90,14 +90,22 @@ class HierarchicalSampler(nn.Module):
         self.perturb = perturb
         self._u = None
 
-    def resample(self, z_vals, weights):
+    def _positions(self, n_rays, device):
+        """The CDF positions to invert: fresh uniform numbers per ray (perturb) or ``linspace(0, 1, n_samples)``."""
         if self.perturb:
-            u = torch.rand(z_vals.shape[0], self.n_samples, device=z_vals.device)
-        else:
-            if self._u is None or self._u.device != z_vals.device or self._u.numel() != self.n_samples:
-                self._u = torch.linspace(0., 1., self.n_samples, device=z_vals.device)   # sampling.py:140
-            u = self._u
-        return ops.hier_resample(z_vals, weights, u)
+            return torch.rand(n_rays, self.n_samples, device=device)
+        if self._u is None or self._u.device != device or self._u.numel() != self.n_samples:
+            self._u = torch.linspace(0., 1., self.n_samples, device=device)   # sampling.py:140
+        return self._u
+
+    def resample(self, z_vals, weights):
+        return ops.hier_resample(z_vals, weights, self._positions(z_vals.shape[0], z_vals.device))
+
+    def sample_pdf(self, bins: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+        """sampling.py:128-169 called by itself: inverse-transform samples (N, n_samples) of the piecewise-constant density
+        ``weights`` (N, B-1) on ``bins`` (N, B).  (``forward`` / ``resample`` run the same kernel with the mid points and the
+        merge folded in.)"""
+        return ops.sample_pdf(bins, weights, self._positions(bins.shape[0], bins.device))
 
     def forward(self, rays_o, rays_d, z_vals, weights):
         new_z, z_comb = self.resample(z_vals, weights)

@@ -296,6 +296,21 @@ def hier_resample(z_vals, weights, u: torch.Tensor) -> Tuple[torch.Tensor, torch
     return new_z, z_comb
 
 
+def sample_pdf(bins, weights, u: torch.Tensor) -> torch.Tensor:
+    """HierarchicalSampler.sample_pdf (sampling.py:128-169) on given bins (N, B) and weights (N, B-1) -> samples (N, S_f);
+    ``u`` as in :func:`hier_resample`."""
+    n, nb = bins.shape
+    bins = _dev(bins, 'bins', (n, nb))
+    weights = _dev(weights.detach(), 'weights', (n, nb - 1))
+    per_ray = int(u.dim() == 2)
+    sf = u.shape[-1]
+    u = _dev(u, 'u', (n, sf) if per_ray else (sf,))
+    samples = torch.empty(n, sf, dtype=torch.float32, device=bins.device)
+    _l.call(bins.device, 'sunerf_sample_pdf', _ptr(bins), _ptr(weights), _ptr(u), per_ray, n, nb, sf, _ptr(samples),
+            _stream(bins.device))
+    return samples
+
+
 def wgrad_split(n_linear: int, n_cus: int = 256, d_filter: int = 256) -> int:
     """Partial sums per layer in sunerf_mlp_wgrad: n_linear * split (* 4 workgroup blocks at d_filter = 512) workgroups
     must fit the chip in ONE wave (one workgroup per CU, all about equally long): 9 layers -> 28 (252 workgroups);

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUNERF_ABI_VERSION 3
+#define SUNERF_ABI_VERSION 4
 
 #define SUNERF_E_BADARG   (-1)   /* null pointer / non-positive size                               */
 #define SUNERF_E_UNSUPPORTED (-2) /* d_filter / n_layers / sample count outside the compiled set     */
@@ -269,6 +269,17 @@ int sunerf_simple_star_field(const float* rays_o, const float* rays_d, const flo
  * ---------------------------------------------------------------------------------------------------------- */
 int sunerf_hier_resample(const float* z_vals, const float* weights, const float* u, int u_per_ray,
                          int64_t n_rays, int n_coarse, int n_fine, float* new_z, float* z_comb, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Inverse-CDF sampling on given bins.
+ * Replaces HierarchicalSampler.sample_pdf called by itself, sampling.py:128-169: pdf = (w + 1e-5) / sum(w + 1e-5),
+ * cdf = [0, cumsum(pdf)], searchsorted(cdf, u, right=True), linear interpolation between the neighbouring bins with the
+ * reference's `denom < 1e-5 -> 1` rule.  `u` as in sunerf_hier_resample.
+ *
+ *   bins [N,B], weights [N,B-1] -> samples [N,S_f]
+ * ---------------------------------------------------------------------------------------------------------- */
+int sunerf_sample_pdf(const float* bins, const float* weights, const float* u, int u_per_ray, int64_t n_rays,
+                      int n_bins, int n_fine, float* samples, void* stream);
 
 #ifdef __cplusplus
 }

@@ -82,20 +82,14 @@ def points_on_rays(rays_o, rays_d, z_vals) -> torch.Tensor:
     return rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
 
 
-def hierarchical_z(z_vals: torch.Tensor, weights: torch.Tensor, n_samples: int,
-                   u: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """HierarchicalSampler.forward + sample_pdf, sampling.py:111-169.
-
-    Returns ``(new_z_samples (N, n_samples), z_vals_combined (N, S + n_samples))``.  ``u`` replaces the
-    deterministic ``linspace`` of :139-141 when the caller wants the ``perturb=True`` branch (:143)."""
-    bins = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
-    w = weights[..., 1:-1]
-    pdf = (w + 1e-5) / torch.sum(w + 1e-5, -1, keepdim=True)
+def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    """HierarchicalSampler.sample_pdf, sampling.py:128-169: inverse-transform samples of the piecewise-constant density
+    ``weights`` (N, B-1) on ``bins`` (N, B) at the CDF positions ``u`` ((S,) shared or (N, S) per ray)."""
+    pdf = (weights + 1e-5) / torch.sum(weights + 1e-5, -1, keepdim=True)
     cdf = torch.cumsum(pdf, dim=-1)
     cdf = torch.concat([torch.zeros_like(cdf[..., :1]), cdf], dim=-1)
-    if u is None:
-        u = torch.linspace(0., 1., n_samples, device=cdf.device)
-        u = u.expand(list(cdf.shape[:-1]) + [n_samples])
+    if u.dim() == 1:
+        u = u.expand(list(cdf.shape[:-1]) + [u.shape[0]])
     u = u.contiguous()
     inds = torch.searchsorted(cdf, u, right=True)
     below = torch.clamp(inds - 1, min=0)
@@ -107,7 +101,19 @@ def hierarchical_z(z_vals: torch.Tensor, weights: torch.Tensor, n_samples: int,
     denom = cdf_hi - cdf_lo
     denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
     t = (u - cdf_lo) / denom
-    new_z = (bin_lo + t * (bin_hi - bin_lo)).detach()
+    return bin_lo + t * (bin_hi - bin_lo)
+
+
+def hierarchical_z(z_vals: torch.Tensor, weights: torch.Tensor, n_samples: int,
+                   u: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """HierarchicalSampler.forward, sampling.py:111-126, around :func:`sample_pdf`.
+
+    Returns ``(new_z_samples (N, n_samples), z_vals_combined (N, S + n_samples))``.  ``u`` replaces the
+    deterministic ``linspace`` of :139-141 when the caller wants the ``perturb=True`` branch (:143)."""
+    bins = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+    if u is None:
+        u = torch.linspace(0., 1., n_samples, device=z_vals.device)
+    new_z = sample_pdf(bins, weights[..., 1:-1], u).detach()
     z_comb, _ = torch.sort(torch.cat([z_vals, new_z], dim=-1), dim=-1)
     return new_z, z_comb
 

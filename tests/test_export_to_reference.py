@@ -169,3 +169,42 @@ def test_density_temperature_state_files_travel_in_both_directions(tmp_path):
     assert back.pixel_intensity_factor == 1e17
     for k, v in back.state_dict().items():
         assert torch.equal(v, sd[k]), k
+
+
+HELPERS_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import ref_import
+ref_import.import_reference()
+import sunerf.model.model as M
+x = torch.from_numpy(np.load(sys.argv[2])['x'])
+torch.manual_seed(0)
+tpe = M.TrainablePositionalEncoding(4, n_freqs=6)
+em = M.EmissionModel(d_filter=32, n_layers=3)
+np.savez(sys.argv[3], tpe=tpe(x).detach().numpy(), tpe_freq=tpe.frequencies.detach().numpy(), sine=M.Sine(1.7)(x).numpy(),
+         pe=M.PositionalEncoding(4, 10)(x).numpy(), em_keys=np.array(sorted(em.state_dict().keys())),
+         em_shapes=np.array([tuple(v.shape) + (0,) * (2 - v.ndim) for _, v in sorted(em.state_dict().items())]))
+'''
+
+
+def test_model_module_helpers_equal_the_reference(tmp_path):
+    """The small public classes of model.py beside ``NeRF`` -- ``Sine``, ``PositionalEncoding`` applied by itself,
+    ``TrainablePositionalEncoding``, ``EmissionModel`` -- against the reference's own, on the same input."""
+    sys.path.insert(0, os.path.join(ROOT, '2024-hl-spi3s-sunerf_amd'))
+    from sunerf.model import model as M
+    x = torch.rand(50, 4, generator=torch.Generator().manual_seed(9)) * 4 - 2
+    inp, out = str(tmp_path / 'x.npz'), str(tmp_path / 'o.npz')
+    np.savez(inp, x=x.numpy())
+    env = {k: v for k, v in os.environ.items() if k != 'PYTHONPATH'}
+    res = subprocess.run([sys.executable, '-c', HELPERS_CHILD, os.path.join(ROOT, 'oracle'), inp, out], env=env,
+                         capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-3000:]
+    want = np.load(out)
+    tpe = M.TrainablePositionalEncoding(4, n_freqs=6)
+    assert np.array_equal(tpe.frequencies.detach().numpy(), want['tpe_freq']) and tpe.d_output == 48
+    assert np.abs(tpe(x).detach().numpy() - want['tpe']).max() <= 1e-6 * np.abs(want['tpe']).max()
+    assert np.array_equal(M.Sine(1.7)(x).numpy(), want['sine'])
+    assert np.array_equal(M.PositionalEncoding(4, 10)(x).numpy(), want['pe'])
+    em = M.EmissionModel(d_filter=32, n_layers=3)
+    assert sorted(em.state_dict().keys()) == list(want['em_keys'])
+    assert [tuple(v.shape) + (0,) * (2 - v.ndim) for _, v in sorted(em.state_dict().items())] == [tuple(r) for r in want['em_shapes']]

@@ -165,7 +165,9 @@ def test_half_precision_against_the_committed_emulated_fixture(ops):
     x = g2['x']
     out = ops.emission_render_fwd(packed, dev(torch.zeros(x.shape[0], 3)), dev(x[:, :3].contiguous()), dev(x[:, 3:].contiguous()),
                                   dev(torch.ones(x.shape[0], 2)), reg_radius=1.2, want_raw=True)
-    assert rel_err(out['raw'][:, 0], g12['g2__inferences_half']) < 1e-4
+    # (g2 is a 64-wide net with outputs of order 0.05: one hidden fp16 value rounded the other way -- the kernel's fp32
+    # pre-activation and the oracle's float64 one differ in the last bits -- moves an output by 2^-11 |w_out| ~ 4e-5)
+    assert (out['raw'][:, 0].cpu() - g12['g2__inferences_half']).abs().max().item() < 5e-5
     params = params_from_golden(g5b, 'sd__coarse_model__')
     packed = ops.PackedMLP([dev(W) for W, _ in params], [dev(b) for _, b in params], precision=ops.PRECISION_HALF)
     out = ops.emission_render_fwd(packed, dev(g5b['rays_o']), dev(g5b['rays_d']), dev(g5b['times']),
