@@ -367,6 +367,11 @@ def main():
         # matrix-pipe work of the forward per algorithmic flop: EXACT 3 fp16 products; FAST 1 fp16 product + two 64-deep
         # fp8 instructions per four 16-deep steps (64 cycles each against 4 x 32: tools/probes/probe_mfma_i8.hip)
         fwd_factor = 1.0 if half else (1.0 + 2.0 * 64.0 / 128.0 if fast else 3.0)
+        # What the arithmetic itself allows on this chip (tools/probes/mfma_sustained.hip, profiles/r2_mfma_sustained.txt: nothing
+        # but the matrix instructions of the mode, operands in registers, every pipe busy, random operands): the board's power
+        # cap holds a pure fp16 MFMA stream at 0.72 of the nominal peak, the FAST group (4 fp16 + 2 fp8 per 64-deep product) at
+        # 0.395 in useful flops, three fp16 products (EXACT) at 0.72 / 3.  No kernel computing these results can exceed it.
+        arithmetic_ceiling = 0.72 if half else (0.395 if fast else 0.24)
         traffic = traffic_source = None
         for tname in ('hbm_traffic.json', 'hbm_traffic_d512.json'):
             tpath = os.path.join(ROOT, 'profiles', tname)
@@ -407,6 +412,9 @@ def main():
                          'frac_of_f32_mfma_peak': achieved / PEAK_F32_MFMA_TFLOPS,
                          # matrix-pipe time actually spent by this kernel, in fp16-MFMA equivalents
                          'executed_frac': achieved * fwd_factor / PEAK_F16_DENSE_TFLOPS,
+                         # ceiling of the forward arithmetic under the power cap (fraction of `peak`, measured) and our share of it
+                         'arithmetic_ceiling_frac': arithmetic_ceiling,
+                         'frac_of_arithmetic_ceiling': achieved / PEAK_F16_DENSE_TFLOPS / arithmetic_ceiling,
                          # the whole step (all kernels) on the same scale: algorithmic FLOPs of the step / ms_per_step
                          'step': {'achieved': step_achieved, 'frac': step_achieved / PEAK_F16_DENSE_TFLOPS,
                                   'flops_per_sample': flops_step}},
