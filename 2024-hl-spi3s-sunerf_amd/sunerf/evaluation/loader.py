@@ -74,8 +74,10 @@ def load_state_file(state_path):
     try:
         return torch.load(state_path, map_location='cpu', weights_only=False)
     except ModuleNotFoundError as err:
-        if err.name not in ('xitorch', 'xitorch.interpolate'):
+        if not (err.name or '').split('.')[0] == 'xitorch':
             raise
+    import importlib.abc
+    import importlib.machinery
     import sys
     import types
 
@@ -84,22 +86,34 @@ def load_state_file(state_path):
             pass
 
     class _StandIn(types.ModuleType):
+        __path__ = []                     # a package: sub-modules of any depth resolve through the finder below
+
         def __getattr__(self, name):
             if name.startswith('__'):
                 raise AttributeError(name)
             cls = type(name, (_Anything,), {'__module__': self.__name__})
             setattr(self, name, cls)
             return cls
-    added = {}
+
+    class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+        def find_spec(self, fullname, path=None, target=None):
+            if fullname == 'xitorch' or fullname.startswith('xitorch.'):
+                return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+            return None
+
+        def create_module(self, spec):
+            return _StandIn(spec.name)
+
+        def exec_module(self, module):
+            pass
+    finder = _Finder()
+    sys.meta_path.insert(0, finder)
     try:
-        for name in ('xitorch', 'xitorch.interpolate', 'xitorch.interpolate.interp1', 'xitorch.interpolate.base_interp',
-                     'xitorch._core', 'xitorch._core.editable_module'):
-            if name not in sys.modules:
-                added[name] = sys.modules[name] = _StandIn(name)
         return torch.load(state_path, map_location='cpu', weights_only=False)
     finally:
-        for name in added:
-            sys.modules.pop(name, None)
+        sys.meta_path.remove(finder)
+        for name in [m for m in sys.modules if m == 'xitorch' or m.startswith('xitorch.')]:
+            del sys.modules[name]
 
 
 class SuNeRFLoader:
