@@ -1,0 +1,20 @@
+"""FAST-mode raw-output error of small networks against the float64 oracle, for the library named by SUNERF_HIP_LIB."""
+import os, sys
+import torch
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(R, '2024-hl-spi3s-sunerf_amd')); sys.path.insert(0, os.path.join(R, 'oracle'))
+import sunerf_oracle as orc
+from sunerf_hip import ops
+for d, L in ((64, 1), (64, 2), (256, 8)):
+    params = orc.init_params(d_filter=d, n_layers=L, seed=5)
+    o, dd = orc.synthetic_rays(8)
+    t = torch.rand(o.shape[0], 1, generator=torch.Generator().manual_seed(2))
+    z = orc.stratified_z(o, dd, orc.linspace_t_vals(32), torch.tensor(1.3), torch.tensor(1.0))
+    pts = orc.points_on_rays(o, dd, z)
+    q = torch.cat([pts, t[:, None].repeat(1, 32, 1)], -1).view(-1, 4)
+    ref = orc.mlp_forward([(W.double(), b.double()) for W, b in params], q.double()).float().view(-1, 32, 2)
+    for mode in (ops.PRECISION_FAST, ops.PRECISION_EXACT):
+        pk = ops.PackedMLP([W.cuda() for W, _ in params], [b.cuda() for _, b in params], precision=mode)
+        raw = ops.emission_render_fwd(pk, o.cuda(), dd.cuda(), t.cuda(), z.cuda(), 1.2, want_raw=True)['raw'].cpu()
+        e = (raw - ref).abs()
+        print(f'd={d} L={L} {ops.PRECISION_NAMES[mode]:5s}: max |err| {e.max().item():.3e}  rms {e.pow(2).mean().sqrt().item():.3e}  (max |raw| {ref.abs().max().item():.3f})')
