@@ -120,18 +120,7 @@ struct PairTmp {
 #ifndef SUNERF_ABL_NO_TRANS
 #define SUNERF_ABL_NO_TRANS 0
 #endif
-#ifndef SUNERF_SCALED_CVT
-#define SUNERF_SCALED_CVT 1       // the remainder's power of two folded into v_cvt_scalef32_pk_fp8_f32 (scale 2^17) instead of a multiply
-#endif
-#ifndef SUNERF_CVT_SCALE
-#define SUNERF_CVT_SCALE 0x1p-17f
-#endif
-#ifndef SUNERF_XL_SHIFT
-#define SUNERF_XL_SHIFT (SUNERF_SCALED_CVT ? 17 : 11)      // log2 of the factor on the fp8 remainder operand
-#endif
-#ifndef SUNERF_PK_SCALE
-#define SUNERF_PK_SCALE 0         // experiment: the remainder's 2^11 as one v_pk_mul_f32 per pair instead of two v_mul_f32
-#endif
+constexpr int XL_SHIFT = 17;      // log2 of the factor on the fp8 remainder operand (folded into its conversion, undone by the block scale)
 #ifndef SUNERF_ABL_NO_L8
 #define SUNERF_ABL_NO_L8 0        // the remainder's scale + fp8 conversion (3 vector instructions per pair micro-op) not issued
 #endif
@@ -471,14 +460,8 @@ struct Mlp {
 #ifndef SUNERF_ABL_NO_AREAD
 #define SUNERF_ABL_NO_AREAD 0     // weight operands are not re-read from LDS (the first group's stay in registers)
 #endif
-#ifndef SUNERF_ABL_NO_DMA
-#define SUNERF_ABL_NO_DMA 0       // no L2 -> LDS weight streaming behind the hidden tiles
-#endif
 #ifndef SUNERF_ABL_NO_TRANS
 #define SUNERF_ABL_NO_TRANS 0     // v_fract instead of v_sin (/ v_cos) in the epilogue
-#endif
-#ifndef SUNERF_ABL_NO_EPI
-#define SUNERF_ABL_NO_EPI 0       // no epilogue at all in hidden tiles (the output set keeps its previous content)
 #endif
 #ifndef SUNERF_BATCH_READS
 #define SUNERF_BATCH_READS 1
@@ -511,40 +494,22 @@ __device__ __forceinline__ void epi_stage_c8(const PairTmp& t, int p, int FP, ha
   // multiply + convert: tools/probes/probe_cvt_scale2.hip) but its BUILTIN: hipcc 7.2 feeds the second half's `old` operand with
   // a neighbouring dword when the two halves of a dword are written by different micro-ops.  Round 2: the instruction through
   // inline asm with the dword tied in and out -- 16 vector instructions fewer per tile in a kernel bound by its one wave's issue
-  // slots (every instruction, s_nop included, costs that wave ~4.8 cycles: tools/probes/probe_valu_cost.hip).
+  // slots (a vector instruction costs that wave ~4.8 cycles, tools/probes/probe_valu_cost.hip).
 #if SUNERF_ABL_NO_L8   // issue-slot ablation: 3 of the ~17 vector instructions of a pair micro-op are not issued
   if (dq & 1) w8h[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.s0, t.s1, w8h[d], true);
   else w8h[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.s0, t.s1, w8h[d], false);
 #else
-#if SUNERF_SCALED_CVT
-  // (the conversion divides by its scale operand; 2^17 puts |remainder| <= 2^-12 at <= 32, i.e. every remainder above 2^-23 into
-  // e4m3's normal range; the matrix instruction's block scale of this operand is 127 - 17)
-  const float cvt_scale = SUNERF_CVT_SCALE;
-  if (dq & 1) {
+  // (the scaled conversion divides by its scale operand; 2^XL_SHIFT puts |remainder| <= 2^-12 at <= 32, i.e. every remainder
+  // above 2^-23 into e4m3's normal range; the matrix instruction's block scale of this operand is 127 - XL_SHIFT.  The head's
+  // conversion merges into the dword's stale content: the other word is rewritten by the neighbouring micro-op anyway)
+  const float cvt_scale = 1.f / (float)(1 << XL_SHIFT);
+  if (dq & 1) {   // the word selectors must be literals
     w8h[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.s0, t.s1, w8h[d], true);
     asm volatile("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(w8l[d]) : "v"(t.r0), "v"(t.r1), "s"(cvt_scale));
   } else {
     w8h[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.s0, t.s1, w8h[d], false);
     asm volatile("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "+v"(w8l[d]) : "v"(t.r0), "v"(t.r1), "s"(cvt_scale));
   }
-#elif SUNERF_PK_SCALE
-  const f32x2 rv = {t.r0, t.r1};
-  const f32x2 rsv = rv * 2048.f;                    // one v_pk_mul_f32
-  const float rs0 = rsv[0], rs1 = rsv[1];
-#else
-  const float rs0 = t.r0 * 2048.f, rs1 = t.r1 * 2048.f;
-#endif
-#if !SUNERF_SCALED_CVT
-  if (dq & 1) {   // the word selector of the builtin must be a literal
-    w8h[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.s0, t.s1, w8h[d], true);
-    w8l[d] = __builtin_amdgcn_cvt_pk_fp8_f32(rs0, rs1, w8l[d], true);
-  } else {
-    // (merging into the dword's stale content instead of a fresh 0 saves a v_mov per conversion: the other word is
-    // rewritten by the next micro-op anyway)
-    w8h[d] = __builtin_amdgcn_cvt_pk_fp8_f32(t.s0, t.s1, w8h[d], false);
-    w8l[d] = __builtin_amdgcn_cvt_pk_fp8_f32(rs0, rs1, w8l[d], false);
-  }
-#endif
 #endif
   if (STASH) {
     if (p < 4) { ch0[2 * p] = t.cpk[0]; ch0[2 * p + 1] = t.cpk[1]; }
@@ -692,14 +657,14 @@ struct Mlp8 : Mlp<D> {
         } else if (sg == 4) {
           accc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(q.al8[slot8], xh8[g], accc, 0, 0, 0, sc.a_lo, 0, 127);
         } else {
-          accc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(q.ah8[slot8], xl8[g], accc, 0, 0, 0, sc.a_hi, 0, 127 - SUNERF_XL_SHIFT);
+          accc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(q.ah8[slot8], xl8[g], accc, 0, 0, 0, sc.a_hi, 0, 127 - XL_SHIFT);
         }
 #if SUNERF_PIN_MFMA
         // the matrix instruction opens its segment: what follows runs in ITS shadow (without this the scheduler is free to
         // move it to the end of the segment, i.e. behind work that was sized for the previous instruction)
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        if (HAS_PREV && !SUNERF_ABL_NO_EPI) {
+        if (HAS_PREV) {
           if (PER == 0) {
             // The previous tile's two accumulators are summed in segment 2, behind two of this tile's matrix instructions
             // (summing at the end of their own tile idles the wave through the latency of its last 16-pass instruction).
@@ -728,7 +693,7 @@ struct Mlp8 : Mlp<D> {
           }
         }
         // weight stream: two pieces per group behind the acquire (page + 3 into the slot everyone left)
-        if ((sg == 1 || sg == 3) && !SUNERF_ABL_NO_DMA) {
+        if (sg == 1 || sg == 3) {
           const int piece = 2 * (((g % GP) + 1) % GP) + (sg == 3 ? 1 : 0);
           if (piece < PIECES) M::issue_piece_dyn(ring, piece);
         }

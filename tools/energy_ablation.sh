@@ -2,8 +2,7 @@
 # What does each kind of work in the forward's hidden tiles cost?  Builds of the library with ONE kind of work removed
 # (render_fwd.hip, SUNERF_ABL_*; operands stay finite, outputs are wrong) against the shipped build, same box, alternating,
 # inference frame 1024^2 x 128, FAST arithmetic forced (the AUTO probe would object to the wrong outputs).
-# Build first:  for v in NO_AREAD NO_DMA NO_TRANS NO_EPI; do tools/build_variant.sh abl_$v -DSUNERF_ABL_$v=1; done
-#               tools/build_variant.sh abl_ALL -DSUNERF_ABL_NO_AREAD=1 -DSUNERF_ABL_NO_DMA=1 -DSUNERF_ABL_NO_EPI=1
+# Build first:  for v in NO_AREAD NO_TRANS NO_L8; do tools/build_variant.sh abl_$v -DSUNERF_ABL_$v=1; done
 cd "$(dirname "$0")/.."
 export SUNERF_FORWARD_PRECISION=fast
 for rep in 1 2; do
