@@ -1,0 +1,67 @@
+"""Randomised parity sweep of the render pass (forward AND parameter gradients) against the CPU oracle: random ray counts,
+sample counts (ragged: not multiples of 32), widths, depths, weight scales and both forward arithmetics.  Development aid, run
+on the GPU box:  python tools/fuzz_parity.py [n_cases] [seed].  Prints one line per case; exits 1 if any case is outside the
+gates (raw 5e-5 abs FAST / 1e-5 EXACT at O(1) outputs, image / weights 1e-4 of the tensor scale, gradients 1.5e-3 rel L2)."""
+import os
+import random
+import sys
+
+import torch
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(R, '2024-hl-spi3s-sunerf_amd')); sys.path.insert(0, os.path.join(R, 'oracle'))
+import sunerf_oracle as orc   # noqa: E402
+from sunerf_hip import ops    # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for case in range(n_cases):
+    d = rng.choice([64, 64, 128, 256, 256, 512])
+    L = rng.randint(1, 8) if d < 512 else rng.randint(1, 3)
+    n = rng.choice([1, 2, 3, 5, 17, 33, 64, 100, 255, 300])
+    S = rng.choice([2, 3, 31, 32, 33, 64, 65, 96, 127, 128, 130, 200])
+    scale = rng.choice([1.0, 1.0, 0.25, 2.0])
+    mode = rng.choice([ops.PRECISION_FAST, ops.PRECISION_EXACT])
+    train = d <= 256 or L <= 3
+    params = orc.init_params(d_filter=d, n_layers=L, seed=1000 + case)
+    params = [((W * scale) if 0 < i < len(params) - 1 else W, b) for i, (W, b) in enumerate(params)]
+    side = int(n ** 0.5) + 1
+    o, dd = orc.synthetic_rays(side)
+    o, dd = o[:n].contiguous(), dd[:n].contiguous()
+    g = torch.Generator().manual_seed(case)
+    t = torch.rand(n, 1, generator=g) * 3
+    z = orc.stratified_z(o, dd, orc.linspace_t_vals(S), torch.tensor(1.3), torch.tensor(1.0))
+    leaves = [(W.clone().requires_grad_(True), b.clone().requires_grad_(True)) for W, b in params]
+    ref = orc.render_pass(leaves, o, dd, t, z)
+    ref['raw'].retain_grad()
+    g_img = torch.randn(n, 1, generator=g)
+    (ref['image'] * g_img).sum().backward()
+    pk = ops.PackedMLP([W.cuda() for W, _ in params], [b.cuda() for _, b in params], precision=mode)
+    out = ops.emission_render_fwd(pk, o.cuda(), dd.cuda(), t.cuda(), z.cuda(), 1.2, want_raw=True, training=train)
+    e_raw = (out['raw'].cpu() - ref['raw'].detach()).abs().max().item() / max(1e-30, ref['raw'].detach().abs().max().item())
+    e_img = ((out['image'].cpu() - ref['image'].detach()).abs().max() / ref['image'].detach().abs().max()).item()
+    e_w = ((out['weights'].cpu() - ref['weights'].detach()).abs().max() / ref['weights'].detach().abs().max()).item()
+    e_g = 0.0
+    if train:
+        gW = [torch.empty_like(W).cuda() for W, _ in params]
+        gb = [torch.empty_like(b).cuda() for _, b in params]
+        ops.emission_render_bwd(pk, o.cuda(), dd.cuda(), z.cuda(), out['raw'], out['stash'], g_img.cuda(), None, 0.0, 1.2, gW, gb)
+        for li, ((W, b), w_, b_) in enumerate(zip(leaves, gW, gb)):
+            for nm, ref_g, got in (('W', W.grad, w_), ('b', b.grad, b_)):
+                if ref_g.norm() > 0:
+                    e = ((got.cpu() - ref_g).norm() / ref_g.norm()).item()
+                    e_g = max(e_g, e)
+                    if os.environ.get('FUZZ_VERBOSE') == str(case):
+                        print(f'      layer {li} {nm}: |ref| {ref_g.norm().item():.3e} rel err {e:.2e}  max|ref| {ref_g.abs().max().item():.2e}')
+        if os.environ.get('FUZZ_VERBOSE') == str(case):
+            gr = ref['raw'].grad.abs().reshape(-1)
+            print('      |g_raw| sorted top 6', [f'{v:.2e}' for v in gr.sort(descending=True)[0][:6].tolist()], 'median', f'{gr.median().item():.2e}', 'nonzero', int((gr > 0).sum()), 'of', gr.numel())
+            print('      |g_img|', g_img.abs().max().item(), 'image', ref['image'].detach().abs().max().item())
+    lim_raw = 2e-4 if mode == ops.PRECISION_FAST else 5e-5
+    ok = e_raw < lim_raw and e_img < 1e-4 and e_w < 1e-4 and e_g < 1.5e-3 and all(torch.isfinite(out[k]).all() for k in ('image', 'weights', 'raw'))
+    bad += not ok
+    print(f'{"ok " if ok else "BAD"} case {case:3d}: d={d:3d} L={L} rays={n:3d} S={S:3d} hidden x{scale:g} {ops.PRECISION_NAMES[mode]:5s} '
+          f'raw {e_raw:.1e} image {e_img:.1e} weights {e_w:.1e} grad {e_g:.1e}', flush=True)
+print(f'{n_cases - bad} of {n_cases} cases inside the gates')
+sys.exit(1 if bad else 0)
