@@ -524,7 +524,25 @@ struct PackTArgs {
   const float* W[SUNERF_MAX_LAYERS];
   int n_linear, D, d_out;
   char* packedT;
+  float* sumsq;      // [SUNERF_MAX_LAYERS] at the tail of packedT: sum of squares of every layer's weight (layers >= 1)
 };
+
+// sum of squares of the hidden / out layers' weights (the per-layer boosts of the backward chain: sunerf_common.h)
+__global__ void layer_sumsq_kernel(PackTArgs a) {
+  const int l = 1 + blockIdx.y;
+  const size_t n = (size_t)((l == a.n_linear - 1) ? a.d_out : a.D) * a.D;
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float w = a.W[l][i];
+    acc += w * w;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(a.sumsq + l, part[0] + part[1] + part[2] + part[3]);
+}
 
 __global__ void pack_mlp_t_kernel(PackTArgs a) {
   const int NT = a.D / 32, KS = a.D / 16;
@@ -538,7 +556,7 @@ __global__ void pack_mlp_t_kernel(PackTArgs a) {
     const int U = (int)(idx / 512), lane = (int)(idx % 512) / 8, e = (int)(idx % 8);
     const int m = lane & 31, h = lane >> 5;
     if (h == 0 && e < a.d_out) w = a.W[a.n_linear - 1][(size_t)e * a.D + 32 * U + m];
-    dst[idx] = (_Float16)w;
+    dst[idx] = (_Float16)ldexpf(w, sunerf_bwd_boost(a.sumsq[a.n_linear - 1], a.D));
     return;
   } else {
     size_t r = idx - n_out;
@@ -550,7 +568,7 @@ __global__ void pack_mlp_t_kernel(PackTArgs a) {
     const int lane = (int)(r / 8), e = (int)(r % 8);
     const int m = lane & 31, h = lane >> 5;
     // A[m][k] = W_l^T[in = 32U+m][out = kmap_hidden(s,h,e)] = W_l[out][in]
-    w = a.W[l][(size_t)kmap_hidden(s, h, e) * a.D + 32 * U + m];
+    w = ldexpf(a.W[l][(size_t)kmap_hidden(s, h, e) * a.D + 32 * U + m], sunerf_bwd_boost(a.sumsq[l], a.D));
     const _Float16 hi = (_Float16)w;
     const _Float16 lo = (_Float16)(w - (float)hi);
     _Float16* blk = dst + n_out + ((size_t)li * NT + U) * KS * 1024;     // block of KS k-steps x 1024 halfs
@@ -564,7 +582,7 @@ __global__ void pack_mlp_t_kernel(PackTArgs a) {
 extern "C" size_t sunerf_packed_mlp_t_bytes(int d_filter, int n_linear) {
   if (d_filter <= 0 || d_filter % 32 || n_linear < 2 || n_linear > SUNERF_MAX_LAYERS) return 0;
   const size_t NT = d_filter / 32, KS = d_filter / 16;
-  return NT * 1024 + (size_t)(n_linear - 2) * NT * KS * 2048;
+  return NT * 1024 + (size_t)(n_linear - 2) * NT * KS * 2048 + SUNERF_MAX_LAYERS * sizeof(float);   // + the layers' sums of squares
 }
 
 extern "C" int sunerf_pack_mlp_t(const float* const* weights_host, int n_linear, int d_filter, int d_out, void* packedT,
@@ -580,8 +598,13 @@ extern "C" int sunerf_pack_mlp_t(const float* const* weights_host, int n_linear,
   a.n_linear = n_linear; a.D = d_filter; a.d_out = d_out; a.packedT = (char*)packedT;
   const size_t NTh = d_filter / 32, KSh = d_filter / 16;
   const size_t total = NTh * 512 + (size_t)(n_linear - 2) * NTh * KSh * 512;   // threads: out halfs + hidden (hi, lo) pairs
+  a.sumsq = (float*)((char*)packedT + NTh * 1024 + (size_t)(n_linear - 2) * NTh * KSh * 2048);
   const int threads = 256;
+  hipError_t me = hipMemsetAsync(a.sumsq, 0, SUNERF_MAX_LAYERS * sizeof(float), (hipStream_t)stream);
+  if (me != hipSuccess) return (int)me;
   SUNERF_CLEAR_ERROR();
+  hipLaunchKernelGGL(layer_sumsq_kernel, dim3(d_filter >= 256 ? 16 : 4, n_linear - 1), dim3(threads), 0, (hipStream_t)stream, a);
+  SUNERF_CHECK_LAUNCH();
   hipLaunchKernelGGL(pack_mlp_t_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0,
                      (hipStream_t)stream, a);
   SUNERF_CHECK_LAUNCH();

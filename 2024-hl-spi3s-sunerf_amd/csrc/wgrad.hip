@@ -265,6 +265,7 @@ struct ReduceArgs {
   float* gb[SUNERF_MAX_LAYERS];
   int n_linear, D, d_out, split;
   int accumulate;     // 0: overwrite grads, 1: add to them
+  const float* sumsq; // per-layer sums of squares at the tail of the transposed image (the boosts folded into W^T), or null
 };
 
 // one thread per element of every dW / db: sums the split partials, unscales, writes nn.Linear layouts
@@ -299,7 +300,11 @@ __global__ void reduce_grads_kernel(ReduceArgs a) {
   const float* p = a.partial + (size_t)layer * a.split * slot + ((size_t)tr * (T + 1) + tc) * 1024 + reg * 64 + lane;
   float sum = 0.f;
   for (int s = 0; s < a.split; ++s) sum += p[(size_t)s * slot];
-  const float inv = sunerf_gscale_inv(*a.g_absmax_bits);
+  // dZ of this layer carries the boosts of every layer above it (sunerf_common.h: sunerf_bwd_boost)
+  int boost = 0;
+  if (a.sumsq)
+    for (int l = layer + 1; l < a.n_linear; ++l) boost += sunerf_bwd_boost(a.sumsq[l], D);
+  const float inv = ldexpf(sunerf_gscale_inv(*a.g_absmax_bits), -boost);
   float* dst = (tc == T) ? a.gb[layer] + j : a.gW[layer] + (size_t)j * cols + k;
   *dst = a.accumulate ? *dst + sum * inv : sum * inv;
 }
@@ -312,13 +317,13 @@ extern "C" size_t sunerf_wgrad_workspace_bytes(int d_filter, int n_linear, int s
   return (size_t)n_linear * split * T * (T + 1) * 1024 * sizeof(float);
 }
 
-extern "C" int sunerf_mlp_wgrad(int d_filter, int n_linear, int d_out, const void* act_stash, const void* dz_stash,
-                                const float* g_raw, const void* g_absmax, int64_t n_rays, int n_samples,
+extern "C" int sunerf_mlp_wgrad(int d_filter, int n_linear, int d_out, const void* packedT, const void* act_stash,
+                                const void* dz_stash, const float* g_raw, const void* g_absmax, int64_t n_rays, int n_samples,
                                 void* workspace, int split, float* const* grad_weights_host,
                                 float* const* grad_biases_host, int accumulate, void* stream) {
   if (!grad_weights_host || !grad_biases_host) return SUNERF_E_BADARG;
   if (n_rays < 0 || n_samples < 2 || split < 1) return SUNERF_E_BADARG;
-  if (n_rays > 0 && (!act_stash || !dz_stash || !g_raw || !g_absmax || !workspace)) return SUNERF_E_BADARG;
+  if (n_rays > 0 && (!packedT || !act_stash || !dz_stash || !g_raw || !g_absmax || !workspace)) return SUNERF_E_BADARG;
   if (n_linear < 2 || n_linear > SUNERF_MAX_LAYERS || d_out < 1 || d_out > 2) return SUNERF_E_UNSUPPORTED;
   if (d_filter != 64 && d_filter != 128 && d_filter != 256 && d_filter != 512) return SUNERF_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
@@ -365,6 +370,8 @@ extern "C" int sunerf_mlp_wgrad(int d_filter, int n_linear, int d_out, const voi
   }
   SUNERF_CHECK_LAUNCH();
   r.partial = (const float*)workspace; r.g_absmax_bits = (const unsigned*)g_absmax; r.n_linear = n_linear; r.D = d_filter;
+  // the boosts sunerf_pack_mlp_t folded into the transposed image the data gradient went through (its tail holds their source)
+  r.sumsq = (const float*)((const char*)packedT + sunerf_packed_mlp_t_bytes(d_filter, n_linear) - SUNERF_MAX_LAYERS * sizeof(float));
   r.d_out = d_out; r.split = split; r.accumulate = accumulate;
   const unsigned tt = (unsigned)wg_tiles(d_filter);
   hipLaunchKernelGGL(reduce_grads_kernel, dim3(tt * (tt + 1) * 1024 / 256, n_linear), dim3(256), 0, st, r);

@@ -44,7 +44,7 @@ _SIGNATURES = {
                                                      ctypes.c_float, ctypes.c_int64, ctypes.c_int, c_f32p, c_void, c_void]),
     'sunerf_mlp_dgrad': (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_f32p, c_void, c_void, c_void,
                                          ctypes.c_int64, ctypes.c_int, c_void]),
-    'sunerf_mlp_wgrad': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void, c_void, c_f32p, c_void,
+    'sunerf_mlp_wgrad': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, c_f32p, c_void,
                                          ctypes.c_int64, ctypes.c_int, c_void, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
                                          c_void]),
@@ -96,7 +96,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.sunerf_abi_version() != 4:
+        if lib.sunerf_abi_version() != 5:
             raise SunerfHipError('libsunerf_hip.so ABI version mismatch')
         _lib = lib
     return _lib

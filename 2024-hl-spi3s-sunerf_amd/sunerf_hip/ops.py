@@ -414,7 +414,7 @@ def mlp_backward(packed: PackedMLP, g_raw, absmax, stash, grad_weights: Sequence
             raise ValueError(f'grad buffer {i} has the wrong shape / layout')
     GW = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grad_weights])
     GB = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grad_biases])
-    _l.call(dev, 'sunerf_mlp_wgrad', D, nl, packed.d_out, _ptr(stash), _ptr(dz), _ptr(g_raw), _ptr(absmax), n, s, _ptr(ws),
+    _l.call(dev, 'sunerf_mlp_wgrad', D, nl, packed.d_out, _ptr(packed.transposed()), _ptr(stash), _ptr(dz), _ptr(g_raw), _ptr(absmax), n, s, _ptr(ws),
             split, GW, GB, int(kernel_accumulate), stream)
     if packed.padded:
         for gw, gb, pw, pb in zip(out_w, out_b, grad_weights, grad_biases):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUNERF_ABI_VERSION 4
+#define SUNERF_ABI_VERSION 5
 
 #define SUNERF_E_BADARG   (-1)   /* null pointer / non-positive size                               */
 #define SUNERF_E_UNSUPPORTED (-2) /* d_filter / n_layers / sample count outside the compiled set     */
@@ -128,7 +128,9 @@ int sunerf_emission_render_fwd(const void* packed, int d_filter, int n_linear, i
  *   sunerf_mlp_dgrad                                         dZ of every layer -> dz_stash (fp16, scaled)
  *   sunerf_mlp_wgrad                                         dW, db of every Linear layer (nn.Linear layouts)
  *
- *   packedT  : sunerf_pack_mlp_t output (transposed fp16 weight image), re-pack after every optimiser step
+ *   packedT  : sunerf_pack_mlp_t output (transposed fp16 weight image, each layer times a power of two chosen from the layer's
+ *              own weights so that the data gradient keeps the scale of g_raw from layer to layer; the same buffer goes to
+ *              sunerf_mlp_dgrad and sunerf_mlp_wgrad), re-pack after every optimiser step
  *   g_reg    : (N,S) gradient w.r.t. the 'regularization' output, or NULL with g_reg_const (the usual
  *              lambda / (N*S) of regularization.mean(), sunerf.py:118-119)
  *   g_absmax : 4-byte device scratch (bit pattern of max |g_raw|; selects the fp16 gradient scale on the device)
@@ -158,10 +160,13 @@ int sunerf_emission_integral_bwd(const float* raw, const float* z_vals, const fl
 int sunerf_mlp_dgrad(const void* packedT, int d_filter, int n_linear, const float* g_raw, const void* g_absmax,
                      const void* act_stash, void* dz_stash, int64_t n_rays, int n_samples, void* stream);
 
-int sunerf_mlp_wgrad(int d_filter, int n_linear, int d_out, const void* act_stash, const void* dz_stash,
-                     const float* g_raw, const void* g_absmax, int64_t n_rays, int n_samples, void* workspace,
-                     int split, float* const* grad_weights_host, float* const* grad_biases_host, int accumulate,
-                     void* stream);
+/* packedT: the SAME transposed image sunerf_mlp_dgrad ran with -- sunerf_pack_mlp_t folds a power of two per layer into it
+ * that keeps the data gradient at the scale of g_raw from layer to layer (fp16 operands), and the sums are divided by
+ * those powers here */
+int sunerf_mlp_wgrad(int d_filter, int n_linear, int d_out, const void* packedT, const void* act_stash,
+                     const void* dz_stash, const float* g_raw, const void* g_absmax, int64_t n_rays, int n_samples,
+                     void* workspace, int split, float* const* grad_weights_host, float* const* grad_biases_host,
+                     int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Density / temperature head (run_density_temperature.py path).

@@ -185,3 +185,30 @@ def test_half_mode_gradients_against_the_fp32_oracle(ops, d_filter, n_layers):
         worst = max(worst, ((W.cpu() - rW).norm() / rW.norm()).item(), ((b.cpu() - rb).norm() / rb.norm()).item())
     print(f'HALF training gradients, d={d_filter} L={n_layers}: worst relative L2 deviation from the fp32 oracle {worst:.2e}')
     assert worst < 1.5e-3
+
+
+@pytest.mark.parametrize('scale,d_filter,n_layers', [(0.25, 64, 7), (0.25, 256, 8), (1.0, 256, 8), (3.0, 128, 5)])
+def test_every_tensor_keeps_its_relative_accuracy_in_deep_attenuating_and_amplifying_nets(ops, scale, d_filter, n_layers):
+    """The data gradient changes scale by the layer's gain every time it passes a layer (x 0.41 at default initialisation,
+    x 0.1 with hidden weights x 0.25: 1e-7 after seven layers, far inside fp16's subnormals -- a randomised sweep found 2e-2
+    on the first layers' gradients there).  sunerf_pack_mlp_t's per-layer powers of two keep the chain at the scale of g_raw:
+    EVERY tensor, first layer included, within 1e-3 (weights) / 2e-3 (biases: plain sums, no averaging factor) of the oracle."""
+    params = orc.init_params(d_filter=d_filter, n_layers=n_layers, seed=1019)
+    params = [((W * scale) if 0 < i < len(params) - 1 else W, b) for i, (W, b) in enumerate(params)]
+    o, d = orc.synthetic_rays(5)
+    o, d = o[:17].contiguous(), d[:17].contiguous()
+    t = torch.rand(17, 1, generator=torch.Generator().manual_seed(16)) * 3
+    z = orc.stratified_z(o, d, orc.linspace_t_vals(128), torch.tensor(1.3), torch.tensor(1.0))
+    leaves = [(W.clone().requires_grad_(True), b.clone().requires_grad_(True)) for W, b in params]
+    ref = orc.render_pass(leaves, o, d, t, z)
+    g_img = torch.randn(17, 1, generator=torch.Generator().manual_seed(3))
+    (ref['image'] * g_img).sum().backward()
+    pk = ops.PackedMLP([W.cuda() for W, _ in params], [b.cuda() for _, b in params])
+    out = ops.emission_render_fwd(pk, o.cuda(), d.cuda(), t.cuda(), z.cuda(), 1.2, training=True)
+    gW = [torch.empty_like(W).cuda() for W, _ in params]
+    gb = [torch.empty_like(b).cuda() for _, b in params]
+    ops.emission_render_bwd(pk, o.cuda(), d.cuda(), z.cuda(), out['raw'], out['stash'], g_img.cuda(), None, 0.0, 1.2, gW, gb)
+    worst_w = max(((g.cpu() - W.grad).norm() / W.grad.norm()).item() for (W, _), g in zip(leaves, gW))
+    worst_b = max(((g.cpu() - b.grad).norm() / b.grad.norm()).item() for (_, b), g in zip(leaves, gb))
+    print(f'hidden x {scale:g}, {n_layers} x {d_filter}: worst weight tensor {worst_w:.2e}, worst bias tensor {worst_b:.2e}')
+    assert worst_w <= 1e-3 and worst_b <= 2e-3
