@@ -35,7 +35,8 @@ def test_size_helpers(lib):
     # + biases + 16 per-layer scale exponents + 16 max|w| scratch words (fp8c stream format)
     assert lib.sunerf_packed_mlp_bytes(256, 9) == steps * 2048 + (8 * 256 + 32) * 4 + 128
     assert lib.sunerf_packed_mlp_bytes(250, 9) == 0 and lib.sunerf_packed_mlp_bytes(256, 1) == 0
-    assert lib.sunerf_packed_mlp_t_bytes(256, 9) == 8 * 1024 + 7 * 8 * 16 * 2048     # out^T hi only; hidden hi + lo
+    # out^T hi only; hidden hi + lo; + the 16 per-layer sums of squares the backward boosts are chosen from
+    assert lib.sunerf_packed_mlp_t_bytes(256, 9) == 8 * 1024 + 7 * 8 * 16 * 2048 + 16 * 4
     # stash: (6 enc + 8 layers x 2 x 16) fragments of 1 KiB per 32-sample chunk, + 1 spare chunk
     assert lib.sunerf_act_stash_bytes(10, 128, 256, 9) == (10 * 4 + 1) * (6 + 8 * 32) * 1024
     assert lib.sunerf_act_stash_bytes(10, 130, 256, 9) == (10 * 5 + 1) * (6 + 8 * 32) * 1024      # ragged last chunk
