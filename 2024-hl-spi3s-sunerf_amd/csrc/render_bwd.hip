@@ -527,21 +527,32 @@ struct PackTArgs {
   float* sumsq;      // [SUNERF_MAX_LAYERS] at the tail of packedT: sum of squares of every layer's weight (layers >= 1)
 };
 
-// sum of squares of the hidden / out layers' weights (the per-layer boosts of the backward chain: sunerf_common.h)
-__global__ void layer_sumsq_kernel(PackTArgs a) {
-  const int l = 1 + blockIdx.y;
+// sum of squares of the hidden / out layers' weights (the per-layer boosts of the backward chain: sunerf_common.h);
+// one workgroup of 1024 threads per layer writes its layer's sum: no atomics, nothing to clear beforehand
+__global__ __launch_bounds__(1024) void layer_sumsq_kernel(PackTArgs a) {
+  const int l = 1 + blockIdx.x;
   const size_t n = (size_t)((l == a.n_linear - 1) ? a.d_out : a.D) * a.D;
   float acc = 0.f;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float w = a.W[l][i];
-    acc += w * w;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  if ((((uintptr_t)a.W[l]) & 15) == 0) {          // rows * D is a multiple of 4 (D % 32 == 0)
+    const f4* w4 = (const f4*)a.W[l];
+    for (size_t i = threadIdx.x; i < n / 4; i += 1024) {
+      const f4 w = w4[i];
+      acc += w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + w[3] * w[3];
+    }
+  } else {
+    for (size_t i = threadIdx.x; i < n; i += 1024) acc += a.W[l][i] * a.W[l][i];
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-  __shared__ float part[4];
+  __shared__ float part[16];
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(a.sumsq + l, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 16; ++i) t += part[i];
+    a.sumsq[l] = t;
+  }
 }
 
 __global__ void pack_mlp_t_kernel(PackTArgs a) {
@@ -600,10 +611,8 @@ extern "C" int sunerf_pack_mlp_t(const float* const* weights_host, int n_linear,
   const size_t total = NTh * 512 + (size_t)(n_linear - 2) * NTh * KSh * 512;   // threads: out halfs + hidden (hi, lo) pairs
   a.sumsq = (float*)((char*)packedT + NTh * 1024 + (size_t)(n_linear - 2) * NTh * KSh * 2048);
   const int threads = 256;
-  hipError_t me = hipMemsetAsync(a.sumsq, 0, SUNERF_MAX_LAYERS * sizeof(float), (hipStream_t)stream);
-  if (me != hipSuccess) return (int)me;
   SUNERF_CLEAR_ERROR();
-  hipLaunchKernelGGL(layer_sumsq_kernel, dim3(d_filter >= 256 ? 16 : 4, n_linear - 1), dim3(threads), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(layer_sumsq_kernel, dim3(n_linear - 1), dim3(1024), 0, (hipStream_t)stream, a);
   SUNERF_CHECK_LAUNCH();
   hipLaunchKernelGGL(pack_mlp_t_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0,
                      (hipStream_t)stream, a);
