@@ -157,3 +157,26 @@ def test_sample_pdf_called_by_itself():
         assert got.shape == (n, sf) and torch.isfinite(got).all()
         assert (got >= b[:, :1] - 1e-6).all() and (got <= b[:, -1:] + 1e-6).all()
         assert (got - want).abs().max().item() <= 1e-5
+
+
+def test_module_call_on_free_standing_points_is_differentiable():
+    """``NeRF.forward(points)`` (model.py:44-57) under autograd: a loss on arbitrary query points reaches the parameters, as in the
+    reference -- values against the reference's own outputs (g2), gradients against the oracle's autograd."""
+    from sunerf.model.model import NeRF
+    g = load_golden('g2_mlp')
+    net = NeRF(d_input=4, d_output=2, n_layers=8, d_filter=64)
+    net.load_state_dict({k[5:].replace('__', '.'): v for k, v in g.items() if k.startswith('net__')}, strict=True)
+    net = net.cuda()
+    x = g['x'].cuda()
+    out = net(x)['inferences']
+    assert out.requires_grad and (out.detach().cpu() - g['inferences']).abs().max().item() < 2e-5
+    probe = torch.randn(out.shape, generator=torch.Generator().manual_seed(4)).cuda()
+    (out * probe).sum().backward()
+    params = [(W.clone().requires_grad_(True), b.clone().requires_grad_(True)) for W, b in params_from_golden(g, 'net__')]
+    (orc.mlp_forward(params, g['x']) * probe.cpu()).sum().backward()
+    lin = net.linears()
+    for (W, b), layer in zip(params, lin):
+        for ref, got in ((W.grad, layer.weight.grad), (b.grad, layer.bias.grad)):
+            assert ((got.cpu() - ref).norm() / ref.norm()).item() <= 1.5e-3
+    with torch.no_grad():
+        assert not net(x)['inferences'].requires_grad
