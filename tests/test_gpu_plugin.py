@@ -176,7 +176,7 @@ def test_module_call_on_free_standing_points_is_differentiable():
     (orc.mlp_forward(params, g['x']) * probe.cpu()).sum().backward()
     lin = net.linears()
     for (W, b), layer in zip(params, lin):
-        for ref, got in ((W.grad, layer.weight.grad), (b.grad, layer.bias.grad)):
-            assert ((got.cpu() - ref).norm() / ref.norm()).item() <= 1.5e-3
+        for ref, got, bound in ((W.grad, layer.weight.grad, 1e-3), (b.grad, layer.bias.grad, 2e-3)):   # 256 points: plain sums
+            assert ((got.cpu() - ref).norm() / ref.norm()).item() <= bound
     with torch.no_grad():
         assert not net(x)['inferences'].requires_grad
