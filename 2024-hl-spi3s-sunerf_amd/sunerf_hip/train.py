@@ -205,7 +205,10 @@ class ClipAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, skip_if_positive: Optional[torch.Tensor] = None):
-        loss = closure() if closure is not None else None
+        loss = None
+        if closure is not None:                 # torch.optim convention (Lightning's automatic optimisation passes the
+            with torch.enable_grad():           # forward + backward of the step as a closure)
+                loss = closure()
         self._collect()
         if skip_if_positive is not None:
             self.nonfinite.copy_(skip_if_positive.reshape(1))

@@ -209,3 +209,40 @@ def test_fit_steps_from_resident_ray_pool(tmp_path):
     assert len(losses) == 2 * len(pool) + 1 and pool.epoch == 3
     assert torch.isfinite(torch.stack(losses)).all()
     assert torch.stack(losses[-5:]).mean().item() < torch.stack(losses[:5]).mean().item()
+
+
+def test_step_driven_the_way_lightning_drives_it():
+    """Lightning 1.9's automatic optimisation (run_emission.py:65-75): ``optimizer.step(closure)`` where the closure runs
+    ``training_step`` + ``backward`` + ``clip_grad_norm_(0.5)`` (``gradient_clip_val``), then ``on_train_batch_end``.  The flat-buffer
+    optimiser must behave like ``torch.optim.Adam`` there: closure evaluated with gradients enabled, torch's clip acting on the
+    gradient views, same parameters afterwards as the fused ``fit_steps`` path (which clips inside the optimiser kernel)."""
+    from sunerf.model.sunerf import EmissionSuNeRFModule, fit_steps
+    g = load_golden('g5_emission_e2e')
+
+    def module():
+        m = EmissionSuNeRFModule(Rs_per_ds=1.0, seconds_per_dt=1.0, image_scaling_config={'vmax': 1, 'a': 0.005},
+                                 sampling_config={'type': 'stratified', 'n_samples': 32, 'perturb': False},
+                                 hierarchical_sampling_config={'type': 'hierarchical', 'n_samples': 32},
+                                 model_config={'d_filter': 64})
+        m.rendering.load_state_dict({k[4:].replace('__', '.'): v for k, v in g.items() if k.startswith('sd__')}, strict=True)
+        return m.cuda()
+    rays = torch.stack([g['rays_o'], g['rays_d']], 1).cuda()
+    batch = {'tracing': {'rays': rays, 'time': g['times'].cuda(), 'target_image': g['target'].cuda()}}
+    fused = module()
+    fit_steps(fused, [batch] * 3)
+    driven = module()
+    (optimizer,), _ = driven.configure_optimizers()
+    losses = []
+    for i in range(3):
+        def closure():
+            optimizer.zero_grad()
+            loss = driven.training_step(batch, i)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(driven.rendering.parameters(), 0.5)
+            return loss
+        losses.append(optimizer.step(closure))
+        driven.on_train_batch_end()
+    assert all(l is not None and torch.isfinite(l) for l in losses) and losses[2] < losses[0]
+    for (name, a), (_, b) in zip(fused.rendering.named_parameters(), driven.rendering.named_parameters()):
+        # same update up to the clip coefficient's rounding (torch: fp32 norm of 36 tensors; fused: one flat fp32 norm)
+        assert (a - b).abs().max().item() <= 2e-6 + 1e-4 * (a.abs().max().item()), name
