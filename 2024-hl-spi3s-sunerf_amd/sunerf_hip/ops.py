@@ -20,13 +20,13 @@ PRECISION_AUTO = -1           # host-side policy (not a kernel mode): FAST while
 PRECISION_NAMES = {PRECISION_FAST: 'fast', PRECISION_EXACT: 'exact', PRECISION_HALF: 'half', PRECISION_AUTO: 'auto'}
 
 # AUTO policy.  FAST (fp16 head + two fp8 correction products) behaves like arithmetic with ~58x the rounding noise of the
-# fp32 reference, EXACT (three fp16 products) like ~7x (tools/precision_scan.py): both are far inside
+# fp32 reference, EXACT (three fp16 products) like ~7x (tests/tools/precision_scan.py): both are far inside
 # the north-star gate (1e-4 relative) for freshly initialised and for trained networks, but the noise of ANY arithmetic
 # -- the reference's included -- is amplified by the network's conditioning, and with all hidden weights x 4 FAST leaves
 # the gate while EXACT stays inside.  So the mode is chosen by MEASUREMENT: every PROBE_EVERY-th parameter version (and the
 # first) PROBE_RAYS rays spread evenly over the render call at hand are rendered in both modes and compared in gate units,
 #     max_ray |fast - exact| / (1e-4 |exact| + 1e-6 max|exact|)      over image, height_map, absorption_map,
-# FAST is kept while that stays below PROBE_LIMIT.  Calibration (tools/probe_calibration.py, hidden weights x 1 ... x 4, two seeds):
+# FAST is kept while that stays below PROBE_LIMIT.  Calibration (tests/tools/probe_calibration.py, hidden weights x 1 ... x 4, two seeds):
 # with 144 rays the probe tracks FAST's true worst gate units against the fp32 reference within 10 % (x 2: probe 0.37 / 0.38, true
 # 0.32 / 0.41; x 3: 0.40 / 0.49, true 0.43 / 0.47; x 4: 1.19 / 0.92, true 1.26 / 0.95), so 0.5 keeps FAST below ~0.55 of the gate.
 PROBE_EVERY = 64

@@ -6,7 +6,7 @@ weights, held PER RAY:
 * weights trained by the REFERENCE's own recipe (fixture g11: 400 CPU steps of Adam + clip + ExponentialLR on the shimmed
   reference, weights moved by up to 140 % of their initial scale): every forward arithmetic must pass;
 * all hidden weights of an 8 x 256 network x 2 and x 4: the forward arithmetics behave like the reference arithmetic with a
-  larger unit round-off (FAST ~58 x, EXACT ~7 x the fp32 noise, measured by tools/precision_scan.py); the network's
+  larger unit round-off (FAST ~58 x, EXACT ~7 x the fp32 noise, measured by tests/tools/precision_scan.py); the network's
   conditioning amplifies all three alike.  x 2: everything passes.  x 4: FAST leaves the gate, EXACT stays inside, and the
   default AUTO policy (sunerf_hip.ops.PackedMLP.probe) must have switched to EXACT by itself;
 * x 8 is the point where the REFERENCE's own fp32 evaluation is further than the gate from the exact (float64) value of

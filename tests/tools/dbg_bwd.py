@@ -1,5 +1,5 @@
 import os, sys, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ('2024-hl-spi3s-sunerf_amd', 'oracle', 'tests'):
     sys.path.insert(0, os.path.join(ROOT, p))
 import sunerf_oracle as orc

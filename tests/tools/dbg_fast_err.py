@@ -1,7 +1,7 @@
 """FAST-mode raw-output error of small networks against the float64 oracle, for the library named by SUNERF_HIP_LIB."""
 import os, sys
 import torch
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, '2024-hl-spi3s-sunerf_amd')); sys.path.insert(0, os.path.join(R, 'oracle'))
 import sunerf_oracle as orc
 from sunerf_hip import ops

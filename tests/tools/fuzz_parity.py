@@ -8,7 +8,7 @@ import sys
 
 import torch
 
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, '2024-hl-spi3s-sunerf_amd')); sys.path.insert(0, os.path.join(R, 'oracle'))
 import sunerf_oracle as orc   # noqa: E402
 from sunerf_hip import ops    # noqa: E402

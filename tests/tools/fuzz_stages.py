@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import torch
 
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, '2024-hl-spi3s-sunerf_amd')); sys.path.insert(0, os.path.join(R, 'oracle')); sys.path.insert(0, os.path.join(R, 'tests'))
 import sunerf_oracle as orc   # noqa: E402
 from conftest import load_golden   # noqa: E402

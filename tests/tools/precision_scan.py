@@ -21,7 +21,7 @@ import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (os.path.join(ROOT, '2024-hl-spi3s-sunerf_amd'), os.path.join(ROOT, 'oracle')):
     sys.path.insert(0, p)
 import sunerf_oracle as orc  # noqa: E402  (the checker)

@@ -2,7 +2,7 @@
 against the fp32 reference arithmetic, for hidden weights scaled x1 ... x4 and several probe sizes."""
 import os, sys
 import torch
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, '2024-hl-spi3s-sunerf_amd')); sys.path.insert(0, os.path.join(R, 'oracle')); sys.path.insert(0, os.path.join(R, 'tests'))
 import sunerf_oracle as orc
 from sunerf_hip import ops
