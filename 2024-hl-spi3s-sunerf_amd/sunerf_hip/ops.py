@@ -290,11 +290,19 @@ def hier_resample(z_vals, weights, u: torch.Tensor) -> Tuple[torch.Tensor, torch
     weights = _dev(weights.detach(), 'weights', (n, sc))
     per_ray = int(u.dim() == 2)
     sf = u.shape[-1]
+    order = None
+    if per_ray:
+        # perturb=True: random positions.  The inverse CDF is monotone, so SORTED positions give sorted new samples and the
+        # kernel merges two ascending runs by rank; handed unsorted ones it falls back to one lane's insertion sort per ray
+        # (2.6 ms instead of 10 us for 3072 rays x 64 + 128 samples).  The new samples are returned in the caller's order.
+        u, order = torch.sort(u, dim=-1)
     u = _dev(u, 'u', (n, sf) if per_ray else (sf,))
     new_z = torch.empty(n, sf, dtype=torch.float32, device=z_vals.device)
     z_comb = torch.empty(n, sc + sf, dtype=torch.float32, device=z_vals.device)
     _l.call(z_vals.device, 'sunerf_hier_resample', _ptr(z_vals), _ptr(weights), _ptr(u), per_ray, n, sc, sf,
             _ptr(new_z), _ptr(z_comb), _stream(z_vals.device))
+    if order is not None:
+        new_z = torch.empty_like(new_z).scatter_(-1, order, new_z)
     return new_z, z_comb
 
 
