@@ -435,9 +435,14 @@ extern "C" int sunerf_dt_integral_bwd(const float* raw, const float* z_vals, con
   if (!g_image || !g_raw || !g_log_abs || !g_vol_c || !g_absmax) return SUNERF_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   hipError_t e;
-  if ((e = hipMemsetAsync(g_absmax, 0, 4, st)) != hipSuccess) return (int)e;
-  if ((e = hipMemsetAsync(g_log_abs, 0, NCH * sizeof(float), st)) != hipSuccess) return (int)e;
-  if ((e = hipMemsetAsync(g_vol_c, 0, sizeof(float), st)) != hipSuccess) return (int)e;
+  if ((char*)g_vol_c == (char*)g_log_abs + NCH * sizeof(float) && (char*)g_absmax == (char*)g_vol_c + sizeof(float)) {
+    // the three small outputs in one buffer (what the Python wrapper passes): one clear instead of three
+    if ((e = hipMemsetAsync(g_log_abs, 0, (NCH + 2) * sizeof(float), st)) != hipSuccess) return (int)e;
+  } else {
+    if ((e = hipMemsetAsync(g_absmax, 0, 4, st)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(g_log_abs, 0, NCH * sizeof(float), st)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(g_vol_c, 0, sizeof(float), st)) != hipSuccess) return (int)e;
+  }
   if (n_rays == 0) return 0;
   const size_t lds = ((size_t)2 * NTAB + 8 + (size_t)DT_RAYS * n_samples * NCH) * sizeof(float);
   if (lds > 160 * 1024) return SUNERF_E_UNSUPPORTED;

@@ -34,6 +34,19 @@ def _grad_targets(params):
     return grads[0::2], grads[1::2]
 
 
+def _scalar_head_slice(scalars):
+    """The slice of a flat gradient bucket that the given 0-d parameters occupy back to back (``ClipAdam`` tags every parameter with
+    ``(owner, offset, numel)``), or None: lets eight scalar gradients be accumulated with one launch instead of eight."""
+    tags = [getattr(p, '_sunerf_bucket', None) for p in scalars]
+    if any(t is None for t in tags):
+        return None
+    owner, first = tags[0][0], tags[0][1]
+    for i, (o, off, k) in enumerate(tags):
+        if o is not owner or off != first + i or k != 1:
+            return None
+    return owner.flat_grads[first:first + len(tags)]
+
+
 def _announce(params):
     """The gradients of ``params`` are final in their flat bucket: let its owner start the all-reduce of that slice while the
     other model's backward still runs (``ClipAdam(overlap=True)``)."""
@@ -248,6 +261,7 @@ class _DtPass(torch.autograd.Function):
             ctx.base = (model.base_log_density, model.base_log_temperature)
             ctx.param_meta = [(p.shape, p.device) for p in params[n_la:]]
             ctx.mlp_params = params[n_la:]
+            ctx.scalar_params = tuple(params[:n_la]) + (vol_c,)
             ctx.save_for_backward(rays_o, rays_d, z_vals, wavelengths, mlp['raw'], mlp['stash'], la, vol_c.detach())
         outs = [out['image'], out['weights'], out['reg_q']]
         non_diff = [out['weights'], out['reg_q']]
@@ -265,7 +279,16 @@ class _DtPass(torch.autograd.Function):
         g_raw, g_la, g_vc, absmax = ops.dt_integral_bwd(raw, z_vals, rays_o, rays_d, wavelengths, ctx.tables[0], ctx.tables[1],
                                                         la, vol_c, ctx.base[0], ctx.base[1], ctx.pixel_factor, ctx.reg_radius,
                                                         g_image.contiguous(), g_reg)
-        head = (None,) * 10 + (g_vc.reshape(()),) + tuple(g_la[i] for i in range(g_la.shape[0]))
+        la_slice = _scalar_head_slice(ctx.scalar_params[:-1])
+        vol_c_param = ctx.scalar_params[-1]
+        if la_slice is not None and getattr(vol_c_param, '_sunerf_bucket', None) is not None and vol_c_param.grad is not None:
+            # the seven absorption scalars sit back to back in the optimiser's flat gradient buffer (the volumetric constant, a
+            # direct parameter of the module, elsewhere in it): two adds instead of eight AccumulateGrad launches
+            la_slice.add_(g_la)
+            vol_c_param.grad.add_(g_vc.reshape(vol_c_param.grad.shape))
+            head = (None,) * (11 + g_la.shape[0])
+        else:
+            head = (None,) * 10 + (g_vc.reshape(()),) + tuple(g_la[i] for i in range(g_la.shape[0]))
         direct = _grad_targets(ctx.mlp_params)
         if direct is not None:
             ops.mlp_backward(ctx.packed, g_raw, absmax, stash, direct[0], direct[1], accumulate=True)

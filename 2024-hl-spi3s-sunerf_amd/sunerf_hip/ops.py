@@ -476,7 +476,8 @@ def simple_star_field(rays_o, rays_d, z_vals, rho_0: float, h0: float, T0: float
 
 def dt_integral_bwd(raw, z_vals, rays_o, rays_d, wavelengths, table_logt, table_resp, log_abs, vol_c, base_log_density,
                     base_log_temperature, pixel_intensity_factor, reg_radius, g_image, g_reg):
-    """-> (g_raw (N,S,2), g_log_abs (7,), g_vol_c (1,), absmax)."""
+    """-> (g_raw (N,S,2), g_log_abs (7,), g_vol_c (1,), absmax).  The two scalar-head gradients are adjacent views of one buffer
+    (``g_log_abs.storage`` holds [7 channels, vol_c, absmax]): one clear in the entry point, one add into a flat gradient bucket."""
     lib = _l.load()
     n, s = z_vals.shape
     dev = z_vals.device
@@ -490,8 +491,8 @@ def dt_integral_bwd(raw, z_vals, rays_o, rays_d, wavelengths, table_logt, table_
         g_reg = _dev(g_reg, 'g_reg', (n, s))
     f32 = dict(dtype=torch.float32, device=dev)
     g_raw = torch.empty(n, s, 2, **f32)
-    g_la, g_vc = torch.empty(7, **f32), torch.empty(1, **f32)
-    absmax = torch.empty(1, dtype=torch.int32, device=dev)
+    small = torch.empty(9, **f32)
+    g_la, g_vc, absmax = small[:7], small[7:8], small[8:9].view(torch.int32)
     _l.call(dev, 'sunerf_dt_integral_bwd', _ptr(raw), _ptr(z_vals), _ptr(rays_o), _ptr(rays_d), _ptr(wavelengths), w,
             _ptr(table_logt), _ptr(table_resp), _ptr(log_abs), _ptr(vol_c), float(base_log_density),
             float(base_log_temperature), float(pixel_intensity_factor), float(reg_radius), n, s, _ptr(g_image),

@@ -43,7 +43,10 @@ def test_dt_forward_matches_reference():
     assert (out['image'].cpu()[g['wavelengths'] == 0] == 0).all()
 
 
-def test_dt_training_step_gradients():
+@pytest.mark.parametrize('flat_bucket', [False, True])
+def test_dt_training_step_gradients(flat_bucket):
+    """``flat_bucket``: with the module's optimiser configured (``ClipAdam``: gradients are views of one flat buffer) the backward
+    kernels add the MLP gradients, the seven absorption scalars' and the volumetric constant's straight into that buffer."""
     from sunerf.model.model import NeRF_DT
     from sunerf.model.sunerf import DensityTemperatureSuNeRFModule
     g = load_golden('g6_dt_e2e')
@@ -59,6 +62,10 @@ def test_dt_training_step_gradients():
     rays = torch.stack([g['rays_o'], g['rays_d']], 1).cuda()
     batch = {'tracing': {'rays': rays, 'time': g['times'].cuda(), 'target_image': g['target'].cuda(),
                          'wavelength': g['wavelengths'].cuda()}}
+    if flat_bucket:
+        (optimizer,), _ = lm.configure_optimizers()
+        optimizer.zero_grad()
+        assert all(hasattr(p, '_sunerf_bucket') for p in lm.rendering.parameters())
     loss = lm.training_step(batch, 0)
     assert abs(loss.item() - g['loss'].item()) < 2e-4 * abs(g['loss'].item())
     loss.backward()
