@@ -31,6 +31,8 @@ struct RenderArgs {
   const float* rays_d;
   const float* times;
   const float* z_vals;
+  const float* points;   // optional [n_rays * S][4]: explicit query points (x, y, z, t) -- NeRF.forward on free-standing points;
+                         // rays_o / rays_d / times / z_vals are then unused and the integral outputs may be null
   int64_t n_rays;
   int S;
   int n_linear;
@@ -940,11 +942,15 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
     const int64_t ray_raw = group * WAVES + wave;
     const bool ray_ok = ray_raw < a.n_rays;
     const int64_t ray = ray_ok ? ray_raw : a.n_rays - 1;
-    const float ox = a.rays_o[ray * 3 + 0], oy = a.rays_o[ray * 3 + 1], oz = a.rays_o[ray * 3 + 2];
-    const float dx = a.rays_d[ray * 3 + 0], dy = a.rays_d[ray * 3 + 1], dz = a.rays_d[ray * 3 + 2];
-    const float tm = a.times[ray];
+    const bool free_points = a.points != nullptr;          // kernel-uniform
+    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 1.f, tm = 0.f;
+    if (!free_points) {
+      ox = a.rays_o[ray * 3 + 0]; oy = a.rays_o[ray * 3 + 1]; oz = a.rays_o[ray * 3 + 2];
+      dx = a.rays_d[ray * 3 + 0]; dy = a.rays_d[ray * 3 + 1]; dz = a.rays_d[ray * 3 + 2];
+      tm = a.times[ray];
+    }
     const float dnorm = sqrtf((dx * dx + dy * dy) + dz * dz);   // torch.norm(rays_d), emission.py:26
-    const float* zrow = a.z_vals + ray * S;
+    const float* zrow = free_points ? nullptr : a.z_vals + ray * S;
 
     float carry_T = 1.f;      // product of (absorption + 1e-10) over all previous samples of the ray
     float carry_z = 0.f;      // z of the previous chunk's last sample
@@ -953,10 +959,14 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
     for (int c = 0; c < n_chunks; ++c) {
       const int i = 32 * c + n;
       const bool valid = i < S;
-      const float z = zrow[valid ? i : S - 1];
+      const float z = free_points ? (float)i : zrow[valid ? i : S - 1];
       // sampling.py:100 -- product and sum rounded separately
-      const float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
-      const float v[4] = {px, py, pz, tm};
+      float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z, pt = tm;
+      if (free_points) {   // the query point itself (model.py:44-57 on arbitrary points); the integral below runs on, unread
+        const f32x4 q = *(const f32x4*)(a.points + ((size_t)ray * S + (valid ? i : S - 1)) * 4);
+        px = q[0]; py = q[1]; pz = q[2]; pt = q[3];
+      }
+      const float v[4] = {px, py, pz, pt};
 
       // training: this chunk's slice of the activation stash (lane-adjusted); enc fragments first
       Rsrc st = make_rsrc(nullptr, 0);
@@ -1211,14 +1221,16 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
       carry_z = __shfl(z, 31, 32);
       if (ray_ok && valid && h == 0) {
         const int64_t o = ray * S + i;
-        a.weights[o] = em;  // un-normalised; finalised below by the same lane
-        a.absorption[o] = absn;
+        if (a.weights) {
+          a.weights[o] = em;  // un-normalised; finalised below by the same lane
+          a.absorption[o] = absn;
+        }
         if (a.raw) { a.raw[o * 2 + 0] = r0; a.raw[o * 2 + 1] = r1; }
         if (a.regularization) a.regularization[o] = fmaxf(pdist - a.reg_radius, 0.f) * (1.f - absn);
       }
     }
     // ---- per-ray finalisation: normalise weights (emission.py:49-50), per-ray outputs ----
-    if (ray_ok && h == 0) {
+    if (ray_ok && h == 0 && a.weights) {
       const float denom = sum_em + 1e-10f;
       for (int c = 0; c < n_chunks; ++c) {
         const int i = 32 * c + n;
@@ -1302,11 +1314,35 @@ extern "C" int sunerf_emission_render_fwd(const void* packed, int d_filter, int 
   if (n_rays == 0) return 0;      // an empty batch is valid (its tensors have null data pointers)
   if (!packed || !rays_o || !rays_d || !times || !z_vals || !image || !weights || !absorption) return SUNERF_E_BADARG;
   RenderArgs a;
-  a.packed = (const char*)packed; a.rays_o = rays_o; a.rays_d = rays_d; a.times = times; a.z_vals = z_vals;
+  a.packed = (const char*)packed; a.rays_o = rays_o; a.rays_d = rays_d; a.times = times; a.z_vals = z_vals; a.points = nullptr;
   a.n_rays = n_rays; a.S = n_samples; a.n_linear = n_linear; a.image = image; a.weights = weights;
   a.absorption = absorption; a.raw = raw; a.height_map = height_map; a.absorption_map = absorption_map;
   a.regularization = regularization; a.reg_radius = reg_radius; a.stash = (char*)act_stash;
   a.scratch = (char*)workspace;
+  if (workspace_bytes < sunerf_render_workspace_bytes(d_filter)) return SUNERF_E_WORKSPACE;
+  switch (d_filter) {
+    case 64: return launch_render<64>(a, precision, (hipStream_t)stream);
+    case 128: return launch_render<128>(a, precision, (hipStream_t)stream);
+    case 256: return launch_render<256>(a, precision, (hipStream_t)stream);
+    case 512: return launch_render<512>(a, precision, (hipStream_t)stream);
+    default: return SUNERF_E_UNSUPPORTED;
+  }
+}
+
+extern "C" int sunerf_mlp_points_fwd(const void* packed, int d_filter, int n_linear, int precision, const float* points,
+                                     int64_t n_points, float* raw, void* act_stash, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  if (n_points < 0 || n_points % 32) return SUNERF_E_BADARG;       // whole 32-point chunks (callers pad)
+  if (n_linear < 2 || n_linear > SUNERF_MAX_LAYERS) return SUNERF_E_UNSUPPORTED;
+  if (precision != SUNERF_PRECISION_FAST && precision != SUNERF_PRECISION_EXACT && precision != SUNERF_PRECISION_HALF)
+    return SUNERF_E_BADARG;
+  if (n_points == 0) return 0;
+  if (!packed || !points || !raw) return SUNERF_E_BADARG;
+  RenderArgs a;
+  a.packed = (const char*)packed; a.rays_o = nullptr; a.rays_d = nullptr; a.times = nullptr; a.z_vals = nullptr; a.points = points;
+  a.n_rays = n_points / 32; a.S = 32; a.n_linear = n_linear; a.image = nullptr; a.weights = nullptr; a.absorption = nullptr;
+  a.raw = raw; a.height_map = nullptr; a.absorption_map = nullptr; a.regularization = nullptr; a.reg_radius = 0.f;
+  a.stash = (char*)act_stash; a.scratch = (char*)workspace;
   if (workspace_bytes < sunerf_render_workspace_bytes(d_filter)) return SUNERF_E_WORKSPACE;
   switch (d_filter) {
     case 64: return launch_render<64>(a, precision, (hipStream_t)stream);

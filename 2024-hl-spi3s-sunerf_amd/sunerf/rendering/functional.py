@@ -4,18 +4,55 @@ import torch
 from sunerf_hip import ops
 
 
-def mlp_points(model, x: torch.Tensor) -> torch.Tensor:
-    """NeRF.forward on arbitrary query points (M, 4) -> (M, d_out) (model.py:44-57).
+class _MlpOnPoints(torch.autograd.Function):
+    """``NeRF.forward`` on free-standing query points (model.py:44-57) as an autograd node: the fused render kernel fed with the
+    points themselves (32 per chunk, no ray, its integral unused), differentiable w.r.t. the model's parameters."""
 
-    Runs the fused render kernel with one two-sample "ray" per point (o = 0, d = xyz, z = 1 => o + d*z = xyz
-    exactly) and returns the raw MLP output of the first sample.  Differentiable w.r.t. the model's parameters like the
-    reference's module call (a loss on free-standing points trains): under autograd it is the same node the generic
-    ``_render`` uses (:func:`mlp_on_rays`)."""
+    @staticmethod
+    def forward(ctx, model, points, *params):
+        training = any(ctx.needs_input_grad[2:])
+        packed = model.packed()
+        out = ops.mlp_points_fwd(packed, points, training=training)
+        if training:
+            ctx.packed, ctx.params, ctx.n_padded = packed, params, out['n_padded']
+            ctx.param_meta = [(p.shape, p.device) for p in params]
+            ctx.save_for_backward(out['stash'])
+        return out['raw'][:, :packed.d_out] if packed.d_out < 2 else out['raw']
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        stash, = ctx.saved_tensors
+        g = g_raw.new_zeros(ctx.n_padded, 2)
+        g[:g_raw.shape[0], :g_raw.shape[1]] = g_raw
+        g = g.view(ctx.n_padded // 32, 32, 2)
+        absmax = g.abs().max().reshape(1).view(torch.int32)      # bit pattern of max |g_raw| (sunerf_common.h: gradient scale)
+        direct = _grad_targets(ctx.params)
+        if direct is not None:
+            ops.mlp_backward(ctx.packed, g, absmax, stash, direct[0], direct[1], accumulate=True)
+            _announce(ctx.params)
+            return (None,) * (2 + len(ctx.params))
+        gW = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[0::2]]
+        gb = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[1::2]]
+        ops.mlp_backward(ctx.packed, g, absmax, stash, gW, gb)
+        grads = []
+        for w, b in zip(gW, gb):
+            grads += [w, b]
+        return (None,) * 2 + tuple(grads)
+
+
+def mlp_points(model, x: torch.Tensor) -> torch.Tensor:
+    """NeRF.forward on arbitrary query points (M, 4) -> (M, d_out) (model.py:44-57): the fused kernel's free-standing-points
+    mode (``sunerf_mlp_points_fwd``), every lane of it a query point.  Differentiable w.r.t. the model's parameters like the
+    reference's module call (a loss on free-standing points trains)."""
     flat = x.reshape(-1, 4)
-    m = flat.shape[0]
-    o = torch.zeros(m, 3, dtype=torch.float32, device=flat.device)
-    z = torch.ones(m, 2, dtype=torch.float32, device=flat.device)
-    return mlp_on_rays(model, o, flat[:, :3].contiguous(), flat[:, 3].contiguous(), z)[:, 0, :]
+    params = []
+    for lin in model.linears():
+        params += [lin.weight, lin.bias]
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        return _MlpOnPoints.apply(model, flat, *params)
+    packed = model.packed()
+    raw = ops.mlp_points_fwd(packed, flat)['raw']
+    return raw[:, :packed.d_out] if packed.d_out < 2 else raw
 
 
 def _grad_targets(params):

@@ -58,6 +58,8 @@ _SIGNATURES = {
                                                c_void]),
     'sunerf_hier_resample': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                              ctypes.c_int, c_f32p, c_f32p, c_void]),
+    'sunerf_mlp_points_fwd': (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_int64, c_f32p,
+                                              c_void, c_void, ctypes.c_size_t, c_void]),
     'sunerf_sample_pdf': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                           c_f32p, c_void]),
     'sunerf_observer_rays': (ctypes.c_int, [c_void, c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
@@ -96,7 +98,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.sunerf_abi_version() != 5:
+        if lib.sunerf_abi_version() != 6:
             raise SunerfHipError('libsunerf_hip.so ABI version mismatch')
         _lib = lib
     return _lib

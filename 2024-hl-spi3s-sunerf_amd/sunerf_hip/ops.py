@@ -282,6 +282,46 @@ def emission_render_fwd(packed: PackedMLP, rays_o, rays_d, times, z_vals, reg_ra
     return out
 
 
+def mlp_points_fwd(packed: PackedMLP, points: torch.Tensor, training: bool = False):
+    """NeRF.forward on free-standing points (M, 4) -> dict(raw (M, 2)[, stash, n_padded]).  The points are padded to whole
+    32-point chunks; ``training=True`` also writes the activation stash :func:`mlp_backward` needs (with ``g_raw`` of shape
+    (n_padded / 32, 32, 2))."""
+    lib = _l.load()
+    m = points.shape[0]
+    dev = points.device
+    points = _dev(points, 'points', (m, 4))
+    if packed.device != dev:
+        raise _l.SunerfHipError('packed weights and points are on different devices')
+    if packed.auto and packed.probe_due and m > 0:
+        # the measured choice of the arithmetic (AUTO) needs rays: PROBE_RAYS of the points as two-sample rays o = 0, d = xyz, z = 1
+        k = min(PROBE_RAYS, m)
+        idx = torch.linspace(0, m - 1, k, device=dev).long()
+        sel = points[idx]
+        packed.probe(torch.zeros(k, 3, device=dev), sel[:, :3].contiguous(), sel[:, 3].contiguous(), torch.ones(k, 2, device=dev), 0.0)
+    m_pad = (m + 31) // 32 * 32
+    if m_pad != m:
+        points = torch.cat([points, points.new_zeros(m_pad - m, 4)])
+    if training and packed.d_filter not in TRAINABLE_D_FILTER:
+        raise NotImplementedError(f'training with d_filter={packed.d_filter} is not implemented (inference only)')
+    ws_bytes = lib.sunerf_render_workspace_bytes(packed.d_filter)
+    ws = None
+    if ws_bytes:
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+        ws = _workspaces.get(key)
+        if ws is None or ws.numel() < ws_bytes:
+            ws = _workspaces[key] = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    raw = torch.empty(m_pad, 2, dtype=torch.float32, device=dev)
+    stash = None
+    if training:
+        stash = torch.empty(lib.sunerf_act_stash_bytes(m_pad // 32, 32, packed.d_filter, packed.n_linear), dtype=torch.uint8, device=dev)
+    _l.call(dev, 'sunerf_mlp_points_fwd', _ptr(packed.buffer), packed.d_filter, packed.n_linear, packed.precision, _ptr(points),
+            m_pad, _ptr(raw), _ptr(stash), _ptr(ws), ws_bytes, _stream(dev))
+    out = {'raw': raw[:m], 'n_padded': m_pad}
+    if training:
+        out['stash'] = stash
+    return out
+
+
 def hier_resample(z_vals, weights, u: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """``u``: (S_f,) shared sample positions (perturb=False) or (N, S_f) per-ray (perturb=True)."""
     lib = _l.load()

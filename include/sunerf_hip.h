@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUNERF_ABI_VERSION 5
+#define SUNERF_ABI_VERSION 6
 
 #define SUNERF_E_BADARG   (-1)   /* null pointer / non-positive size                               */
 #define SUNERF_E_UNSUPPORTED (-2) /* d_filter / n_layers / sample count outside the compiled set     */
@@ -116,6 +116,15 @@ int sunerf_emission_render_fwd(const void* packed, int d_filter, int n_linear, i
                                float* height_map, float* absorption_map, float* regularization,
                                float reg_radius, void* act_stash, void* workspace, size_t workspace_bytes,
                                void* stream);
+
+/* NeRF.forward on free-standing query points, model.py:44-57 (positional encoding + sine MLP, no ray, no integral): the fused
+ * render kernel fed with explicit points.  points [M,4] = (x, y, z, t), M a multiple of 32 (callers pad); raw [M,2].
+ * act_stash (optional): as in sunerf_emission_render_fwd with n_rays = M / 32, n_samples = 32 -- sunerf_mlp_dgrad /
+ * sunerf_mlp_wgrad then take g_raw [M/32, 32, 2] (a loss on arbitrary points trains, as the reference's module call does).
+ * Serves evaluation/loader.py:load_coords (volume queries) at the kernel's full rate. */
+int sunerf_mlp_points_fwd(const void* packed, int d_filter, int n_linear, int precision, const float* points,
+                          int64_t n_points, float* raw, void* act_stash, void* workspace, size_t workspace_bytes,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Backward of the fused render pass (training).  The reference has no backward code of its own: these entry points

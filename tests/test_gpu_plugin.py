@@ -179,4 +179,9 @@ def test_module_call_on_free_standing_points_is_differentiable():
         for ref, got, bound in ((W.grad, layer.weight.grad, 1e-3), (b.grad, layer.bias.grad, 2e-3)):   # 256 points: plain sums
             assert ((got.cpu() - ref).norm() / ref.norm()).item() <= bound
     with torch.no_grad():
-        assert not net(x)['inferences'].requires_grad
+        plain = net(x)['inferences']
+        assert not plain.requires_grad and torch.equal(plain, out.detach())
+        # ragged counts: padded to whole 32-point chunks inside, every point independent of its neighbours
+        for m in (1, 31, 33, 250):
+            assert torch.equal(net(x[:m])['inferences'], plain[:m]), m
+        assert net(x[:0])['inferences'].shape == (0, 2)
