@@ -185,3 +185,19 @@ def test_module_call_on_free_standing_points_is_differentiable():
         for m in (1, 31, 33, 250):
             assert torch.equal(net(x[:m])['inferences'], plain[:m]), m
         assert net(x[:0])['inferences'].shape == (0, 2)
+
+
+@pytest.mark.parametrize('d_filter,n_layers', [(64, 3), (128, 2), (256, 8), (512, 3)])
+@pytest.mark.parametrize('mode', ['fast', 'exact', 'half'])
+def test_points_mode_is_the_same_arithmetic_as_a_ray_through_the_point(d_filter, n_layers, mode):
+    """``sunerf_mlp_points_fwd`` against the render pass on two-sample rays o = 0, d = xyz, z = 1 (whose samples ARE the points):
+    bit-identical raw outputs for every width and forward arithmetic."""
+    from sunerf_hip import ops
+    precision = {'fast': ops.PRECISION_FAST, 'exact': ops.PRECISION_EXACT, 'half': ops.PRECISION_HALF}[mode]
+    params = orc.init_params(d_filter=d_filter, n_layers=n_layers, seed=77)
+    pk = ops.PackedMLP([W.cuda() for W, _ in params], [b.cuda() for _, b in params], precision=precision)
+    pts = (torch.rand(100, 4, generator=torch.Generator().manual_seed(1)) * 2.4 - 1.2).cuda()
+    got = ops.mlp_points_fwd(pk, pts)['raw']
+    ref = ops.emission_render_fwd(pk, torch.zeros(100, 3, device='cuda'), pts[:, :3].contiguous(), pts[:, 3].contiguous(),
+                                  torch.ones(100, 2, device='cuda'), 0.0, want_raw=True)['raw'][:, 0]
+    assert torch.equal(got, ref)
