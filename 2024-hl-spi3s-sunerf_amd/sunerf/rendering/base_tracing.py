@@ -79,8 +79,12 @@ class SuNeRFRendering(nn.Module):
         return torch.relu(distance - 1.2 / self.Rs_per_ds) * (1 - regularizing_quantity)
 
     def _hooks_replaced(self, owner) -> bool:
-        """True when the object's class overrides one of the hooks that ``owner``'s fused ``forward`` has built in."""
-        return any(getattr(type(self), hook) is not getattr(owner, hook) for hook in ('raw2outputs', '_render', 'regularization'))
+        """True when the fused ``forward`` of ``owner`` does not apply: the object's class overrides one of the hooks it has built
+        in, or a field model is a module the kernels do not know -- any ``nn.Module`` answering ``{'inferences': ...}`` may be
+        passed as ``model=`` (the reference renders ``MHDModel`` cubes that way, evaluation/image_render.py:252-268)."""
+        if any(getattr(type(self), hook) is not getattr(owner, hook) for hook in ('raw2outputs', '_render', 'regularization')):
+            return True
+        return not all(isinstance(m, NeRF) or hasattr(m, 'field_on_rays') for m in (self.coarse_model, self.fine_model))
 
     def forward(self, rays_o, rays_d, times, wavelengths=None):
         """base_tracing.py:46-111: coarse pass -> hierarchical resampling on its weights -> fine pass -> the three maps."""

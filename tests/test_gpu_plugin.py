@@ -201,3 +201,35 @@ def test_points_mode_is_the_same_arithmetic_as_a_ray_through_the_point(d_filter,
     ref = ops.emission_render_fwd(pk, torch.zeros(100, 3, device='cuda'), pts[:, :3].contiguous(), pts[:, 3].contiguous(),
                                   torch.ones(100, 2, device='cuda'), 0.0, want_raw=True)['raw'][:, 0]
     assert torch.equal(got, ref)
+
+
+def test_any_module_can_be_the_field_model():
+    """``model=`` takes any ``nn.Module`` answering ``{'inferences', 'log_abs', 'vol_c'}`` on (M, 4) points -- the reference renders its MHD
+    cubes that way (evaluation/image_render.py:252-268).  A torch-written wrapper around the analytic star must render, through the
+    generic forward, what the fused ``SimpleStar`` path renders (fixture g9's reference outputs)."""
+    from torch import nn
+    from sunerf.model.stellar_model import SimpleStar
+    from sunerf.rendering.density_temperature import DensityTemperatureRadiativeTransfer as DT
+
+    class Wrapped(nn.Module):                      # no `field_on_rays`, not a NeRF: unknown to the kernels
+        def __init__(self):
+            super().__init__()
+            self.star = SimpleStar()
+
+        def forward(self, x):
+            return self.star(x)
+
+    g = load_golden('g9_simple_star')
+    mod = DT(Rs_per_ds=1, model=Wrapped, model_config={}, sampling_config={'type': 'stratified', 'n_samples': 24, 'perturb': False},
+             hierarchical_sampling_config={'type': 'hierarchical', 'n_samples': 24},
+             response_table=(g['aia_logte'].numpy(), g['aia_tresp'].numpy())).cuda()
+    with torch.no_grad():
+        for m in (mod.coarse_model, mod.fine_model):
+            for w in (94, 131, 171, 193, 211, 304, 335):
+                m.star.log_absortpion[str(w)].copy_(g[f'la__{w}'])
+            m.star.volumetric_constant.copy_(g['vol_c'])
+        got = mod(g['rays_o'].cuda(), g['rays_d'].cuda(), g['times'].cuda(), g['wavelengths'].cuda())
+    for k in ('coarse_image', 'fine_image', 'image'):
+        for c in range(g['out__' + k].shape[1]):
+            assert gate_units(got[k][:, c], g['out__' + k][:, c]) <= 1.0, (k, c)
+    assert (got['image'].cpu()[g['wavelengths'] == 0] == 0).all()
