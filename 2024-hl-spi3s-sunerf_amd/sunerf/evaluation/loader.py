@@ -17,7 +17,6 @@ from typing import Optional, Tuple
 import numpy as np
 import torch
 
-from sunerf.rendering.functional import mlp_points
 from sunerf_hip.rays import pose_spherical, render_frame
 
 AU_IN_SOLAR_RADII = 215.03215567054764      # (1 * u.AU).to(u.solRad), IAU 2012 / 2015 nominal values
@@ -193,10 +192,11 @@ class SuNeRFLoader:
         ``(..., 4)`` = (x, y, z, t)."""
         target_shape = query_points_npy.shape[:-1]
         flat = torch.from_numpy(np.ascontiguousarray(query_points_npy)).float().reshape(-1, 4)
-        out = torch.empty(flat.shape[0], self.model.out_layer.out_features, dtype=torch.float32)
+        parts = []
         for b in range(0, flat.shape[0], batch_size):
-            out[b:b + batch_size] = mlp_points(self.model, flat[b:b + batch_size].to(self.device)).cpu()
-        return out.view(*target_shape, -1).numpy()
+            answer = self.model(flat[b:b + batch_size].to(self.device))      # any field model: NeRF (fused points mode), SimpleStar, ...
+            parts.append((answer['inferences'] if isinstance(answer, dict) else answer).cpu())      # D3 resolved: the tensor
+        return torch.cat(parts, 0).view(*target_shape, -1).numpy()
 
 
 class ModelLoader(SuNeRFLoader):

@@ -135,6 +135,14 @@ def test_sunerf_loader_roundtrip(tmp_path):
     want = orc.mlp_forward(orc.params_from_state_dict(sd, 'fine_model.'), torch.from_numpy(pts).reshape(-1, 4))
     assert got.shape == (5, 7, 2)
     assert np.abs(got.reshape(-1, 2) - want.numpy()).max() < 1e-4 * np.abs(want.numpy()).max()
+    # ... of any field model (loader.py:119-134 calls the module): the analytic star behind a ModelLoader
+    from sunerf.evaluation.loader import ModelLoader
+    from sunerf.model.stellar_model import SimpleStar
+    star = SimpleStar()
+    field = ModelLoader(rendering=rendering, model=star, ref_map={'meta': {'t_obs': '2022-01-01T00:00:00.000'}})
+    got = field.load_coords(pts, batch_size=16)
+    want = orc.simple_star_field(torch.from_numpy(pts).reshape(-1, 4), *(star.stellar_parameters[k].detach().cpu() for k in ('rho_0', 'h0', 'T0', 'Rs')))
+    assert got.shape == (5, 7, 2) and np.abs(got.reshape(-1, 2) - want.numpy()).max() < 1e-5 * np.abs(want.numpy()).max()
 
 
 def test_reference_written_state_file_loads_into_fused_classes():
