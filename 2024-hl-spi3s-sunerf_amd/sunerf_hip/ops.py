@@ -5,7 +5,7 @@ kernels of ``csrc/``.
 """
 import ctypes
 import os
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 
