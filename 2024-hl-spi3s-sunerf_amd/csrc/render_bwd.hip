@@ -536,7 +536,14 @@ __global__ __launch_bounds__(1024) void layer_sumsq_kernel(PackTArgs a) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   if ((((uintptr_t)a.W[l]) & 15) == 0) {          // rows * D is a multiple of 4 (D % 32 == 0)
     const f4* w4 = (const f4*)a.W[l];
-    for (size_t i = threadIdx.x; i < n / 4; i += 1024) {
+    const size_t n4 = n / 4;
+    size_t i = threadIdx.x;
+    for (; i + 3 * 1024 < n4; i += 4 * 1024) {      // four independent 16-byte loads in flight per lane: one CU streams a layer
+      const f4 w0 = w4[i], w1 = w4[i + 1024], w2 = w4[i + 2048], w3 = w4[i + 3072];
+      acc += (w0[0] * w0[0] + w0[1] * w0[1] + w0[2] * w0[2] + w0[3] * w0[3]) + (w1[0] * w1[0] + w1[1] * w1[1] + w1[2] * w1[2] + w1[3] * w1[3])
+           + (w2[0] * w2[0] + w2[1] * w2[1] + w2[2] * w2[2] + w2[3] * w2[3]) + (w3[0] * w3[0] + w3[1] * w3[1] + w3[2] * w3[2] + w3[3] * w3[3]);
+    }
+    for (; i < n4; i += 1024) {
       const f4 w = w4[i];
       acc += w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + w[3] * w[3];
     }

@@ -1,7 +1,7 @@
 """End-to-end sanity run of the training path on one MI355X: the emission module (8 x 256, 64 coarse samples + 128 resampled ones: 64 + 192 network evaluations per ray) trained with
 ``fit_steps`` -- fused loss, overlapped bucket, clip + Adam kernels, ExponentialLR, AUTO forward arithmetic re-probed every 64
 parameter versions -- on an analytic target (limb-darkened disk + exponential corona seen from 8 longitudes), batches of 3072 rays
-like config/sunerfs_simple_star.yaml:8.  Prints loss / PSNR every 100 steps and the rate.  python tools/mini_train.py [steps]"""
+like config/sunerfs_simple_star.yaml:8.  Prints loss / PSNR every 100 steps and the rate.  python tools/mini_train.py [steps] [d_filter]"""
 import os
 import sys
 import time
@@ -15,6 +15,7 @@ from sunerf_hip import ops                                        # noqa: E402
 from sunerf_hip.rays import observer_rays                          # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 800
+d_filter = int(sys.argv[2]) if len(sys.argv) > 2 else 256          # 512 = the reference's default width (model.py:16)
 torch.manual_seed(0)
 views = [observer_rays(96, theta=-0.3 + 0.785 * k, phi=0.1 * (k % 3 - 1)) for k in range(8)]
 rays_o, rays_d = torch.cat([v[0] for v in views]), torch.cat([v[1] for v in views])
@@ -24,7 +25,7 @@ times = torch.zeros(rays_o.shape[0], 1, device=rays_o.device)
 mod = EmissionSuNeRFModule(Rs_per_ds=1.0, seconds_per_dt=1.0, image_scaling_config={'vmax': 1, 'a': 0.005},
                            sampling_config={'type': 'stratified', 'n_samples': 64, 'perturb': True},
                            hierarchical_sampling_config={'type': 'hierarchical', 'n_samples': 128, 'perturb': True},
-                           model_config={'d_filter': 256}, lr_config={'start': 5e-4, 'end': 5e-5, 'iterations': steps}).cuda()
+                           model_config={'d_filter': d_filter}, lr_config={'start': 5e-4, 'end': 5e-5, 'iterations': steps}).cuda()
 mod.strict_finite_check = False                      # no host read inside the step; checked at the end
 n, B = rays_o.shape[0], 3072
 
