@@ -6,6 +6,7 @@
                     all-reduced gradients) as two kernels over ONE flat parameter / gradient / moment buffer.
 """
 import ctypes
+import os
 from typing import Dict, Iterable, Optional, Sequence
 
 import torch
@@ -185,7 +186,7 @@ class ClipAdam(torch.optim.Optimizer):
         """Called by a backward node whose kernels have accumulated the FINAL gradients of ``params`` into the bucket: starts
         the all-reduce of that slice right away (``overlap=True`` and a process group; no-op otherwise).  The collective is
         ordered behind the gradient kernels on the current stream and runs beside whatever is launched next."""
-        if not self.overlap or not self._world():
+        if not self.overlap or not self._world() or os.environ.get('SUNERF_NO_OVERLAP'):      # (the env switch: rehearsals / A-B runs)
             return
         spans = sorted(p._sunerf_bucket[1:] for p in params)
         lo, hi = spans[0][0], spans[-1][0] + spans[-1][1]

@@ -116,8 +116,11 @@ def two_pass_rate(dev, world, rays_o, rays_d, times, target, batch, samples, ste
         target = torch.rand(target.shape[0], 7, generator=torch.Generator().manual_seed(1)).to(dev)
     else:
         rendering = EmissionRadiativeTransfer(**cfg).to(dev)
-    # overlap: the fine model's slice of the bucket is all-reduced while the coarse model's backward runs
-    opt = ClipAdam(rendering.parameters(), lr=1e-4, max_norm=0.5, overlap=True)
+    # overlap (the fine model's slice of the bucket all-reduced while the coarse model's backward runs) is what
+    # `fit_steps` uses; in this SUB-line of a driver-run record it is opt-in (SUNERF_BENCH_OVERLAP=1): the early collectives have
+    # run with RCCL at world size 1 and with gloo at 2 - 3 ranks only, a 4-rank gloo rehearsal on ONE card took seconds per step in
+    # them, and a stall here would cost the whole N-GPU record for a 2 MB all-reduce's worth of overlap
+    opt = ClipAdam(rendering.parameters(), lr=1e-4, max_norm=0.5, overlap=bool(os.environ.get('SUNERF_BENCH_OVERLAP')))
     n_batches = max(1, rays_o.shape[0] // batch)
 
     def step(i):
