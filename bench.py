@@ -165,8 +165,9 @@ def two_pass_rate(dev, world, rays_o, rays_d, times, target, batch, samples, ste
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (default: 40 in train mode = 1 s of timed work, visible to a '
+                                                            '1 Hz utilisation sampler; 8 frames in fwd mode = 2 s)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed steps before (default 4 / 2)')
     ap.add_argument('--res', type=int, default=1024)
     ap.add_argument('--samples', type=int, default=128)
     ap.add_argument('--batch', type=int, default=32768, help='rays per rank and optimiser step (train mode)')
@@ -180,6 +181,10 @@ def main():
                                                          'samples per ray (reported under "dt_two_pass")')
     ap.add_argument('--d-filter', type=int, default=D_FILTER, help='MLP width (headline: 256; 512 = reference default)')
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 40 if args.mode == 'train' else 8
+    if args.warmup is None:
+        args.warmup = 4 if args.mode == 'train' else 2
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # `python bench.py --gpus N` started directly: become the launcher.  A child process, started before anything here
         # has touched a GPU (never an exec: see the GPU-box rules), one rank per GPU over RCCL; its output is relayed.
