@@ -14,8 +14,10 @@ for f in pack sampler rays render_fwd render_bwd dt train_step; do
   hipcc $COMMON -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c -o "$OBJ/$f.o" "$f.hip" &
   pids+=($!)
 done
-hipcc $COMMON "$@" -c -o "$OBJ/wgrad.o" wgrad.hip &
-pids+=($!)
+for f in wgrad bwd_pipe; do     # accumulators in AGPRs (bwd_pipe.hip: 128 per weight-gradient wave, W^T fragments per data-gradient wave)
+  hipcc $COMMON "$@" -c -o "$OBJ/$f.o" "$f.hip" &
+  pids+=($!)
+done
 for p in "${pids[@]}"; do wait "$p"; done     # set -e: a failed compile fails the build
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/pack.o "$OBJ"/sampler.o "$OBJ"/rays.o "$OBJ"/render_fwd.o "$OBJ"/render_bwd.o "$OBJ"/dt.o "$OBJ"/train_step.o "$OBJ"/wgrad.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/pack.o "$OBJ"/sampler.o "$OBJ"/rays.o "$OBJ"/render_fwd.o "$OBJ"/render_bwd.o "$OBJ"/dt.o "$OBJ"/train_step.o "$OBJ"/wgrad.o "$OBJ"/bwd_pipe.o
 echo "built $OUT"

@@ -1,0 +1,956 @@
+// Layer-pipelined backward of the sine MLP (gfx950, d_filter = 256): data AND weight gradients of every Linear layer from
+// the activation stash, without ever writing the hidden layers' dZ to HBM.
+//
+// Replaces what torch.autograd derives from sunerf/model/model.py:44-57 (reference root), like sunerf_mlp_dgrad +
+// sunerf_mlp_wgrad, whose two kernels move 16.4 KB per sample of an 8 x 256 network (cos in, dZ out; H and dZ in).  Here the
+// workgroup that produces dZ_{l-1} hands it to the workgroup that consumes it through the XCD's L2, so the backward reads H
+// and cos once (8.2 KB per sample) plus the top layer's dZ (0.5 KB written once by the prologue kernel, read twice).
+//
+//   dW_l[j][k]  = sum_n dZ_l[j][n] H_{l-1}[k][n]        db_l[j] = sum_n dZ_l[j][n]
+//   dZ_{l-1}[k][n] = (sum_j W_l[j][k] dZ_l[j][n]) cos(Z_{l-1})[k][n]
+//
+// STAGES.  A CU cannot hold a whole layer (dW_l alone is all 256 AGPRs of its four waves), two can: stage l is a PAIR of
+// workgroups, workgroup j of it owning the 128 features J_j = [128 j, 128 j + 128) of layer l-1 -- the columns J_j of dW_l
+// (32 accumulator tiles = 128 registers per wave), the rows J_j of W_l^T (each wave keeps ITS output tile's 16 A fragments
+// in registers for the whole launch: 64 registers, + 64 for the low parts) and the fragments J_j of H_{l-1}, cos_{l-1} and
+// dZ_{l-1}.  Per 32-sample chunk it takes in dZ_l (16 KB, from the two workgroups of stage l+1), H_{l-1}[J] and cos_{l-1}[J]
+// (8 KB each, HBM, every byte read once chip-wide) by LDS-DMA, and puts out its half of dZ_{l-1} (8 KB).  A pipeline is
+// the stages l = n_act-1 ... 1 plus the in-layer stage (dW_0 from dZ_0 and the encoding stash): 2 (n_linear - 1) workgroups,
+// all on ONE XCD so that the hand-off never leaves that XCD's L2 (plain stores stay in the L2 they were written to; the
+// consumer's LDS-DMA reads are `sc1`, i.e. served by L2 past its own stale L1).  8 x 256 network: 16 workgroups per pipeline,
+// two pipelines per XCD, 16 in all, each working through 1/16 of the chunks.
+//
+// The top stage's input, dZ of the last activation layer, and the out layer's own dW / db come from a streaming prologue
+// kernel (g_raw, cos and H of the last activation layer -> dZ_top, 512 B per sample).
+//
+// HAND-OFF.  Per link (pipeline, layer) a ring of RING chunk slots (16 KB each) in device memory and four monotonic
+// counters, each with ONE writer: prod[j] = chunks whose half producer j has stored AND drained (in-order vmcnt: known
+// NBUF iterations later), cons[j] = chunks consumer j has landed in its LDS.  A consumer may fetch chunk c once
+// min(prod) > c; a producer may overwrite slot c % RING once min(cons) > c - RING.  The counters are polled AHEAD by LDS-DMA
+// (a 4-byte-per-lane DMA into a small LDS slot, issued NBUF-1 iterations before its value is needed and covered by the same
+// counted vmcnt wait as the chunk's data), so that a wave never waits for a flag round trip unless the partner really is
+// late; only then it falls back to a bounded spin.  Placement is CHECKED, not assumed: every workgroup publishes its XCC_ID,
+// and a class (blockIdx % 8) that does not sit on one XCD makes the whole launch give up (status word; the reduce kernel then
+// writes NaN gradients, which the optimiser's non-finite guard skips, and the host falls back to the two-kernel backward).
+// Every spin is bounded by s_memrealtime and watches the status word, so the grid always drains.
+#include "grad_common.h"
+
+namespace {
+
+constexpr int PD = 256, PKS = PD / 16, PNT = PD / 32, PT = 8;   // d_filter, fragments / tiles per layer, workspace tiles
+constexpr int WG = 512;                 // pipelined kernel: eight waves, two per SIMD
+constexpr int WG_PRE = 256;             // prologue kernel
+constexpr int NBUF = 4;                 // staging buffers per workgroup (chunks in flight: NBUF - 1)
+constexpr int RING = 16;                // chunk slots per hand-off ring
+constexpr int SLOT = PKS * 1024;        // one chunk of dZ: 16 fragments
+constexpr int BUF_HID = 32 * 1024;      // hidden stage staging: dZ_l 16 | H[J] 8 | cos[J] 8 KiB
+constexpr int BUF_IN = 16 * 1024;       // in-layer stage staging: dZ_0[J] 8 | enc 6 (| 2 unused) KiB
+constexpr int BUF_PRE = 35 * 1024;      // prologue staging: H 16 | cos 16 | dZ_out operand tile 2 KiB | g_raw of the chunk 256 B
+constexpr unsigned SPIN_LIMIT = 50000000u;   // s_memrealtime ticks (100 MHz): 0.5 s
+
+// status codes (word 0 of the control block)
+constexpr unsigned ST_OK = 0, ST_START_TIMEOUT = 1, ST_PLACEMENT = 2, ST_WAIT_TIMEOUT = 3;
+
+struct PipeArgs {
+  const char* packedT;
+  const char* act_stash;
+  const char* dz_top;       // [chunk][16 fragments] fp16, written by the prologue kernel
+  char* rings;              // [pipeline][link n_act-1][RING][SLOT] + scratch for the dummy stores
+  unsigned* ctrl;           // control block (zeroed before every launch)
+  float* partial;           // [layer 0 .. n_act-1][pipeline][72 tiles][16][64]
+  const float* g_raw;
+  const unsigned* g_absmax_bits;
+  float* partial_out;       // prologue: [workgroup][9 tiles][16][64] (out layer)
+  int64_t n_chunks_total;
+  int S, n_chunks;          // samples per ray, chunks per ray
+  int n_linear, d_out;
+  int NP, NPX;              // pipelines in all / per XCD class
+  int hi_only;
+  int xflags;               // timing experiments (results are garbage): 4 = no matrix work, 8 = H / cos always from one chunk (L2),
+                            // 16 = no hand-off (every stage reads dz_top, nobody waits)
+  unsigned* dbg;            // optional [workgroup][8]: loop ticks, fallback spins / ticks of the input and output link, chunks, layer, pipeline
+};
+
+// control block: word 0 status, 1 arrived, 8..15 XCC masks per class; counters from word 64, each on a 128-byte line
+__host__ __device__ inline size_t ctrl_counter_word(int n_links, int P, int link, int which) {
+  return 64 + (((size_t)P * n_links + link) * 4 + which) * 32;
+}
+__host__ __device__ inline size_t ctrl_bytes(int NP, int n_links) { return (64 + (size_t)NP * n_links * 4 * 32) * 4; }
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
+  return __hip_atomic_load((const gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned* p, unsigned v) {
+  __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// LDS-DMA of one 1 KiB piece (16 bytes per lane); POLICY 0 = default, 1 = nt (read-once HBM stream), 2 = sc1 (handed-off
+// bytes: past this CU's L1)
+template <int POLICY>
+__device__ __forceinline__ void dma_piece(const char* src_lane, unsigned lds_dst) {
+  const unsigned d = __builtin_amdgcn_readfirstlane(lds_dst);
+  if (POLICY == 1) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(src_lane), "s"(d) : "memory");
+  else if (POLICY == 2) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" :: "v"(src_lane), "s"(d) : "memory");
+  else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src_lane), "s"(d) : "memory");
+}
+// the same with a wave-uniform source (scalar base) and the lane part (lane * 16) as the 32-bit vector offset
+template <int POLICY>
+__device__ __forceinline__ void dma_piece_s(const char* src_uniform, unsigned voff, unsigned lds_dst) {
+  const unsigned d = __builtin_amdgcn_readfirstlane(lds_dst);
+  if (POLICY == 1) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 nt" :: "v"(voff), "s"(d), "s"(src_uniform) : "memory");
+  else if (POLICY == 2) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 sc1" :: "v"(voff), "s"(d), "s"(src_uniform) : "memory");
+  else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" :: "v"(voff), "s"(d), "s"(src_uniform) : "memory");
+}
+// counter poll by LDS-DMA: lane i's dword lands at lds_dst + 4 i
+__device__ __forceinline__ void dma_poll(const unsigned* src_lane, unsigned lds_dst) {
+  const unsigned d = __builtin_amdgcn_readfirstlane(lds_dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off sc1" :: "v"(src_lane), "s"(d) : "memory");
+}
+
+// one accumulator tile -> workspace [reg 16][lane 64]: buffer stores (one resource, the lane part as the only address VGPR;
+// with plain pointers hipcc forms all 128 addresses of a wave's eight tiles first -- 256 VGPRs -- and spills)
+__device__ __forceinline__ void store_tile(const f32x16& t, float* dst) {
+  const Rsrc r = make_rsrc(dst, 16 * 64 * 4);
+  const int lo4 = (int)(threadIdx.x & 63u) * 4;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    // read out through an asm with an AGPR operand: a plain element read makes hipcc give the whole loop-carried tile a VGPR
+    // home and copy it to AGPRs and back around every matrix instruction
+    const float te = t[g];
+    unsigned tv;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(tv) : "a"(te));
+    __builtin_amdgcn_raw_buffer_store_b32(tv, r, lo4, g * 256, 0);
+    // (keeps the accumulator reads next to their stores: hoisted together, the reads of a wave's eight tiles want 128 VGPRs)
+    if ((g & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Accumulate into an AGPR-resident tile.  Written as asm because hipcc (ROCm 7.2) keeps loop-carried accumulators of the
+// builtin in VGPRs when they would fit there and copies 16 registers to AGPRs and back around every instruction; the "+a"
+// operand pins the tile.  Hazards: the operands come from v_mov / ds_read (hardware-interlocked); nothing reads a tile
+// between two of its own accumulations (>= 7 other matrix instructions apart) and the final read-out is preceded by
+// drain_matrix_pipe().
+__device__ __forceinline__ void mfma_agpr(f32x16& acc, const half8& a, const half8& b) {
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void drain_matrix_pipe() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
+
+__device__ __forceinline__ void dz_tile(const f32x16& acc, const half8& c0, const half8& c1, half8& d0, half8& d1) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    d0[j] = (_Float16)sunerf_sat16(acc[j] * (float)c0[j]);
+    d1[j] = (_Float16)sunerf_sat16(acc[8 + j] * (float)c1[j]);
+  }
+}
+
+// 4-byte LDS words by LDS address: a `volatile` access through a generic pointer becomes a FLAT load, which hipcc follows
+// with s_waitcnt vmcnt(0) -- draining the whole LDS-DMA queue every iteration
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+__device__ __forceinline__ unsigned lds_ld(unsigned addr) { return *(volatile lds_u32*)(uintptr_t)addr; }
+__device__ __forceinline__ void lds_st(unsigned addr, unsigned v) { *(volatile lds_u32*)(uintptr_t)addr = v; }
+
+__device__ __forceinline__ void barrier_mem() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// bounded wait of one lane for min(*a0, *a1) >= need; returns false (and raises the status word) on timeout / foreign abort
+__device__ __forceinline__ bool spin_until(const unsigned* a0, const unsigned* a1, unsigned need, unsigned* status, unsigned& have, unsigned* stat) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  stat[0] += 1;
+  for (;;) {
+    const unsigned v0 = ld_agent(a0), v1 = ld_agent(a1);
+    have = v0 < v1 ? v0 : v1;
+    if ((int)(have - need) >= 0) { stat[1] += (unsigned)(__builtin_amdgcn_s_memrealtime() - t0); return true; }
+    if (ld_agent(status) != ST_OK) return false;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT) {
+      st_agent(status, ST_WAIT_TIMEOUT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// hidden stage l (n_act-1 >= l >= 1), workgroup j of the pair
+// ------------------------------------------------------------------------------------------------------------------
+template <bool HI_ONLY, bool TOP>
+__device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int P, int l, int j, int64_t cbeg, int n_my) {
+  // EIGHT waves, two per SIMD, with different jobs (one register budget of 256 per wave, two simple loops instead of one that
+  // needs 400 registers -- hipcc rotated whole accumulator tiles between the register-file halves in that one):
+  //   waves 0..3 ("data"):   dH tile 4 j + w = W_l^T dZ_l (W^T fragments resident in AGPRs), dZ_{l-1} = dH * cos -> ring
+  //   waves 4..7 ("weight"): the 4 x 2 accumulator tiles of dW_l[:, J_j] (+ db_l), the hand-off protocol (wave 4)
+  // The two waves of a SIMD share its matrix pipe; while one issues LDS reads, DMA pieces or the epilogue, the other's
+  // matrix instructions run.
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_act = a.n_linear - 1, n_links = n_act - 1;
+  const StashLayout SL(PD, a.n_linear);
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  const unsigned lds_dummy = lds0 + NBUF * BUF_HID;
+  const unsigned lds_poll = lds_dummy + 1024;
+  const unsigned lds_abort = lds_poll + NBUF * 256;      // [2]
+  unsigned* status = a.ctrl;
+  const unsigned voff = lane * 16;
+
+  char* ring_in = TOP ? nullptr : a.rings + ((size_t)P * n_links + l) * RING * SLOT;
+  char* ring_out = a.rings + ((size_t)P * n_links + (l - 1)) * RING * SLOT;
+  const size_t act_chunk = SL.chunk_bytes();
+  const char* srcH0 = a.act_stash + SL.h_off(l - 1) + (size_t)(8 * j) * 1024;
+  const char* srcC0 = a.act_stash + SL.c_off(l - 1) + (size_t)(8 * j) * 1024;
+  const int64_t safe = cbeg < a.n_chunks_total ? cbeg : a.n_chunks_total - 1;     // a chunk inside the stashes for surplus DMA
+
+  // wave-uniform sources / LDS destination of the chunk being fetched (nxt = it + NBUF - 1), set at the top of an iteration
+  const char *nz = nullptr, *nh = nullptr, *nc = nullptr;
+  unsigned ndst = 0;
+  bool nreal = false;
+  // (called with nxt = 0, 1, 2, ... in turn: the addresses advance by additions -- 64-bit multiplications here cost every wave
+  // several hundred cycles per chunk)
+  const char* const safe_h = srcH0 + (size_t)safe * act_chunk;
+  const char* const safe_c = srcC0 + (size_t)safe * act_chunk;
+  const char* const safe_z = TOP ? a.dz_top + (size_t)safe * SLOT : ring_in;
+  const char *run_h = srcH0 + (size_t)cbeg * act_chunk, *run_c = srcC0 + (size_t)cbeg * act_chunk;
+  const char* run_z = TOP ? a.dz_top + (size_t)cbeg * SLOT : ring_in;
+  int run_slot = 0;
+  auto next_chunk = [&](int nxt) __attribute__((always_inline)) {
+    nreal = nxt < n_my;
+    ndst = lds0 + (nxt & (NBUF - 1)) * BUF_HID;
+    nz = nreal ? run_z : safe_z;
+    nh = nreal ? run_h : safe_h;
+    nc = nreal ? run_c : safe_c;
+    run_h += act_chunk;
+    run_c += act_chunk;
+    if (TOP) run_z += SLOT;
+    else {
+      run_slot = run_slot + 1 == RING ? 0 : run_slot + 1;
+      run_z = run_slot == 0 ? ring_in : run_z + SLOT;
+    }
+  };
+  // LDS image of a chunk: pieces 0..15 dZ fragments, 16..23 H[J], 24..31 cos[J]
+  auto piece_z = [&](int f) __attribute__((always_inline)) {
+    const unsigned dst = nreal ? ndst + f * 1024 : lds_dummy;
+    if (TOP) dma_piece_s<1>(nz + (size_t)f * 1024, voff, dst);
+    else dma_piece_s<2>(nz + (size_t)f * 1024, voff, dst);
+  };
+  auto piece_h = [&](int f) __attribute__((always_inline)) { dma_piece_s<1>(nh + (size_t)f * 1024, voff, nreal ? ndst + (16 + f) * 1024 : lds_dummy); };
+  auto piece_c = [&](int f) __attribute__((always_inline)) { dma_piece_s<1>(nc + (size_t)f * 1024, voff, nreal ? ndst + (24 + f) * 1024 : lds_dummy); };
+
+  if (wave < 4) {
+    // =============================================== data-gradient waves ===============================================
+    constexpr int NO = 2, NP_D = 6;                  // output stores / DMA pieces per iteration: dZ fragments w, 4 + w, 8 + w, 12 + w
+                                                     // and the cos fragments 2 w, 2 w + 1 of this wave's own tile
+    constexpr int PF = 4;                            // B fragments requested PF k-steps ahead of their matrix instructions
+    const int U = 4 * j + wave;                      // output tile: features 32 U .. 32 U + 31 of layer l-1
+    const int li = (a.n_linear - 2) - l;
+    half8 wt_hi[PKS], wt_lo[HI_ONLY ? 1 : PKS];
+    {
+      const char* blk = a.packedT + (size_t)PNT * 1024 + ((size_t)li * PNT + U) * PKS * 2048 + lane * 16;
+#pragma unroll
+      for (int s = 0; s < PKS; ++s) {
+        wt_hi[s] = *(const half8*)(blk + s * 2048);
+        if constexpr (!HI_ONLY) wt_lo[s] = *(const half8*)(blk + s * 2048 + 1024);
+      }
+#pragma unroll
+      for (int s = 0; s < PKS; ++s) {
+        asm volatile("" : "+a"(wt_hi[s]));
+        if constexpr (!HI_ONLY) asm volatile("" : "+a"(wt_lo[s]));
+      }
+    }
+    char* scratch = a.rings + (size_t)a.NP * n_links * RING * SLOT + ((size_t)blockIdx.x * 4 + wave) * 2048;
+    // prologue iterations -(NBUF-1) .. -1: DMA only (+ two dummy stores: the same vmcnt accounting as a full iteration)
+    bool stop = false;
+    for (int it = -(NBUF - 1); it < 0; ++it) {
+      asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NO + 2 * (NP_D + NO)) : "memory");
+      barrier_mem();
+      const unsigned ab = lds_ld(lds_abort + (it & 1) * 4);
+      next_chunk(it + NBUF - 1);
+      piece_z(wave); piece_z(4 + wave); piece_z(8 + wave); piece_z(12 + wave); piece_c(2 * wave); piece_c(2 * wave + 1);
+      const Rsrc sc = make_rsrc(scratch, 2048);
+      const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+      buf_store(zero, sc, 0);
+      buf_store(zero, sc, 1024);
+      if (ab) { stop = true; break; }
+    }
+    unsigned long long ph[4] = {0, 0, 0, 0};      // SUNERF_PIPE_DEBUG: shader clocks in wait / barrier / k-steps / epilogue
+    const bool stamp = a.dbg != nullptr;
+    char* out_z = ring_out;                        // ring slot of this iteration's output
+    int out_slot = 0;
+    for (int it = 0; it < (stop ? 0 : n_my); ++it) {
+      const int buf = it & (NBUF - 1);
+      unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      if (stamp) s0 = __builtin_amdgcn_s_memtime();
+      // the pieces of chunk `it` (issued NBUF-1 iterations ago) have landed once at most the two younger iterations'
+      // operations and the output stores issued behind those pieces are outstanding; the stores of chunk it - NBUF, issued
+      // before them, are then complete as well (vmcnt counts in issue order) -- which is what wave 4 publishes
+      asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NO + 2 * (NP_D + NO)) : "memory");
+      if (stamp) s1 = __builtin_amdgcn_s_memtime();
+      barrier_mem();
+      if (stamp) s2 = __builtin_amdgcn_s_memtime();
+      // abort word of this iteration: requested now, looked at when the iteration's work is done (every wave leaves in the same
+      // iteration, so the barrier counts still agree; what a doomed iteration computes and stores is garbage either way)
+      const unsigned ab = lds_ld(lds_abort + (it & 1) * 4);
+      next_chunk(it + NBUF - 1);
+      const char* B = smem + (size_t)buf * BUF_HID;
+      f32x16 dacc = {0};
+      half8 bf[PF + 1];
+      half8 c0f, c1f;
+#pragma unroll
+      for (int s = 0; s < PF; ++s) bf[s] = *(const half8*)(B + s * 1024 + lane * 16);
+#pragma unroll
+      for (int ks = 0; ks < PKS; ++ks) {
+        if (ks + PF < PKS) bf[(ks + PF) % (PF + 1)] = *(const half8*)(B + (ks + PF) * 1024 + lane * 16);
+        if constexpr (!HI_ONLY) dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt_lo[ks], bf[ks % (PF + 1)], dacc, 0, 0, 0);
+        dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt_hi[ks], bf[ks % (PF + 1)], dacc, 0, 0, 0);
+        if (ks == 1) piece_z(wave);
+        if (ks == 3) piece_z(4 + wave);
+        if (ks == 5) piece_z(8 + wave);
+        if (ks == 7) piece_z(12 + wave);
+        if (ks == 9) piece_c(2 * wave);
+        if (ks == 11) piece_c(2 * wave + 1);
+        if (ks == PKS - PF) {            // the last B fragment has been requested: cos of this wave's tile
+          c0f = *(const half8*)(B + (24 + 2 * wave) * 1024 + lane * 16);
+          c1f = *(const half8*)(B + (25 + 2 * wave) * 1024 + lane * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (stamp) { asm volatile("" :: "v"(dacc)); s3 = __builtin_amdgcn_s_memtime(); }
+      // dZ_{l-1} = dH * cos (fp16, saturating) -> ring slot, fragments 2 U, 2 U + 1 of the chunk
+      half8 d0, d1;
+      dz_tile(dacc, c0f, c1f, d0, d1);
+      const Rsrc ro = make_rsrc(out_z, SLOT);
+      buf_store(d0, ro, (2 * U) * 1024);
+      buf_store(d1, ro, (2 * U + 1) * 1024);
+      out_slot = out_slot + 1 == RING ? 0 : out_slot + 1;
+      out_z = out_slot == 0 ? ring_out : out_z + SLOT;
+      if (stamp) {
+        const unsigned long long s4 = __builtin_amdgcn_s_memtime();
+        ph[0] += s1 - s0; ph[1] += s2 - s1; ph[2] += s3 - s2; ph[3] += s4 - s3;
+      }
+      if (ab) break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    barrier_mem();
+    if (stamp && wave == 1 && lane == 0) {
+      unsigned* d = a.dbg + 256 * 8 + (size_t)blockIdx.x * 8;
+      for (int k = 0; k < 4; ++k) d[k] = (unsigned)(ph[k] >> 4);
+    }
+    return;
+  }
+
+  // ================================================= weight-gradient waves =================================================
+  const int v = wave - 4;
+  const bool gatew = v == 0;
+  // block of this wave: row tiles 4 rq .. +3 (features of dZ_l), column tiles 2 cq, 2 cq + 1 of J_j; db_l (workgroup 0 of the
+  // pair): every wave sums two of its four row tiles
+  const int rq = v >> 1, cq = v & 1;
+  const int r0 = 4 * rq, c0 = 2 * cq;
+  const bool do_bias = j == 0;
+  f32x16 acc[4][2];
+  float bsum[2] = {0.f, 0.f};
+  {
+    // zero tiles DEFINED in AGPRs (0 * 0 + 0 by the matrix pipe): a `= {0}` gives the loop-carried tiles a VGPR home and hipcc
+    // then copies 16 registers into AGPRs in front of every matrix instruction and back behind it
+    half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+    asm volatile("s_nop 7" : "+v"(hz));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, 0" : "=a"(acc[i][0]) : "v"(hz));
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, 0" : "=a"(acc[i][1]) : "v"(hz));
+    }
+  }
+  // counters: input link l (producers 0, 1; my consumer count), output link l-1 (my producer count; consumers 0, 1 -- only
+  // consumer j on link 0, whose in-layer stage reads its own half)
+  unsigned* in_prod0 = a.ctrl + ctrl_counter_word(n_links, P, TOP ? 0 : l, 0);
+  unsigned* in_prod1 = a.ctrl + ctrl_counter_word(n_links, P, TOP ? 0 : l, 1);
+  unsigned* my_cons = a.ctrl + ctrl_counter_word(n_links, P, TOP ? 0 : l, 2 + j);
+  unsigned* my_prod = a.ctrl + ctrl_counter_word(n_links, P, l - 1, j);
+  unsigned* out_cons0 = a.ctrl + ctrl_counter_word(n_links, P, l - 1, 2 + (l == 1 ? j : 0));
+  unsigned* out_cons1 = a.ctrl + ctrl_counter_word(n_links, P, l - 1, 2 + (l == 1 ? j : 1));
+  const unsigned* poll_src = (lane & 3) == 0 ? in_prod0 : (lane & 3) == 1 ? in_prod1 : (lane & 3) == 2 ? out_cons0 : out_cons1;
+  unsigned have_in = 0, have_out = 0;      // wave 4: newest known min(prod) of the input link / min(cons) of the output link
+  unsigned st_in[2] = {0, 0}, st_out[2] = {0, 0};       // (lane 0 of wave 4) fallback spins and the 100 MHz ticks they took
+  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+  const unsigned laneoff = tr_lane_offset(lane);
+
+  // gate of iteration `itn` (wave 4): its DMA (chunk itn + NBUF - 1) needs that chunk published by both producers, its output
+  // (slot itn % RING) needs chunk itn - RING landed in both consumers.  Normally the polled counters already say so.
+  auto gate = [&](int itn) __attribute__((always_inline)) {
+    const int nx = itn + NBUF - 1;
+    const bool need_in = !TOP && nx < n_my && (int)(have_in - (unsigned)(nx + 1)) < 0;
+    const bool need_out = itn >= RING && (int)(have_out - (unsigned)(itn - RING + 1)) < 0;
+    if (need_in || need_out) {
+      bool ok = true;
+      if (lane == 0) {
+        if (need_in) ok = spin_until(in_prod0, in_prod1, (unsigned)(nx + 1), status, have_in, st_in);
+        if (ok && need_out) ok = spin_until(out_cons0, out_cons1, (unsigned)(itn - RING + 1), status, have_out, st_out);
+        if (!ok) lds_st(lds_abort + (itn & 1) * 4, 1u);
+      }
+      have_in = __builtin_amdgcn_readfirstlane(have_in);
+      have_out = __builtin_amdgcn_readfirstlane(have_out);
+    }
+  };
+  if (gatew) {
+    if (lane == 0) { lds_st(lds_abort, 0u); lds_st(lds_abort + 4, 0u); }      // the abort words are only ever SET (by a failed gate)
+    gate(-(NBUF - 1));
+  }
+
+  bool aborted = false;
+  // per iteration: two pieces (H fragments v, 4 + v -- the data waves, which have the shorter instruction stream, fetch the
+  // dZ and cos fragments); wave 4 also the flag store and the poll.
+  // top(): counted wait, barrier, abort word, sources of the next chunk, wave 4's publication and poll.
+  unsigned long long tw = 0, tb = 0;       // SUNERF_PIPE_DEBUG: shader clocks in the counted wait / the barrier
+  const bool stamp = a.dbg != nullptr;
+  auto top = [&](int it) __attribute__((always_inline)) {
+    const int nxt = it + NBUF - 1;
+    unsigned long long sa = 0, sb = 0;
+    if (stamp) sa = __builtin_amdgcn_s_memtime();
+    if (gatew) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * (2 + 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * 2) : "memory");
+    if (stamp) sb = __builtin_amdgcn_s_memtime();
+    barrier_mem();
+    if (stamp) { tw += sb - sa; tb += __builtin_amdgcn_s_memtime() - sb; }
+    const unsigned ab = lds_ld(lds_abort + (it & 1) * 4);     // looked at by the caller when the iteration's work is done
+    next_chunk(nxt);
+    if (gatew) {
+      // publish: chunk `it` has landed in this workgroup (its ring slot may be overwritten); the outputs of chunk
+      // it - NBUF are in L2 (the data waves' counted waits in front of the barrier).  One store instruction, lanes 0 and 1.
+      // Then the poll whose value is read NBUF-1 iterations on.
+      if (lane < 2) {
+        const int pv = lane == 0 ? it + 1 : it - NBUF + 1;
+        st_agent(lane == 0 ? my_cons : my_prod, (unsigned)(pv > 0 ? pv : 0));
+      }
+      dma_poll(poll_src, lds_poll + (nxt & (NBUF - 1)) * 256);
+    }
+    return ab;
+  };
+  for (int it = -(NBUF - 1); it < 0; ++it) {      // prologue iterations: DMA only
+    const unsigned ab = top(it);
+    piece_h(v); piece_h(4 + v);
+    if (ab) { aborted = true; break; }
+    if (gatew && it + 1 < n_my) gate(it + 1);
+  }
+  unsigned long long ph[4] = {0, 0, 0, 0};      // SUNERF_PIPE_DEBUG: shader clocks in top (wait + barrier + publication) / operand reads + gate / matrix
+  tw = 0; tb = 0;
+  for (int it = 0; it < (aborted ? 0 : n_my); ++it) {
+    const int buf = it & (NBUF - 1);
+    unsigned long long s0 = 0, s1 = 0, s2 = 0;
+    if (stamp) s0 = __builtin_amdgcn_s_memtime();
+    const unsigned ab = top(it);
+    if (stamp) s1 = __builtin_amdgcn_s_memtime();
+    // operand bases of this wave's block: row tiles r0.. of the dZ fragments, column tiles c0.. of the H fragments; the tile
+    // and k-step parts of the addresses are immediates
+    const unsigned bufA = lds0 + buf * BUF_HID + laneoff + r0 * 2048, bufB = lds0 + buf * BUF_HID + laneoff + 16 * 1024 + c0 * 2048;
+    half4 alo[2][4], ahi[2][4], blo[2][2], bhi[2][2];
+    tr_issue_imm<0 * 2048>(bufA, alo[0][0], ahi[0][0]); tr_issue_imm<1 * 2048>(bufA, alo[0][1], ahi[0][1]);
+    tr_issue_imm<2 * 2048>(bufA, alo[0][2], ahi[0][2]); tr_issue_imm<3 * 2048>(bufA, alo[0][3], ahi[0][3]);
+    tr_issue_imm<0 * 2048>(bufB, blo[0][0], bhi[0][0]); tr_issue_imm<1 * 2048>(bufB, blo[0][1], bhi[0][1]);
+    piece_h(v);
+    piece_h(4 + v);
+    typedef __attribute__((address_space(3))) v4u lds_v4u;
+    v4u pw = {0, 0, 0, 0};
+    if (gatew) pw = *(const lds_v4u*)(uintptr_t)(lds_poll + buf * 256);     // the poll that landed with this iteration's chunk
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (gatew) {     // -> gate of the next iteration (in the shadow of the operand reads' wait)
+      asm volatile("" : "+v"(pw));
+      const unsigned pi = pw[0] < pw[1] ? pw[0] : pw[1], qo = pw[2] < pw[3] ? pw[2] : pw[3];
+      if ((int)(pi - have_in) > 0) have_in = pi;
+      if ((int)(qo - have_out) > 0) have_out = qo;
+      have_in = __builtin_amdgcn_readfirstlane(have_in);
+      have_out = __builtin_amdgcn_readfirstlane(have_out);
+      if (it + 1 < n_my) gate(it + 1);
+    }
+    if (stamp) s2 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(alo[0][i]), "+v"(ahi[0][i]));
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) asm volatile("" : "+v"(blo[0][jj]), "+v"(bhi[0][jj]));
+    tr_issue_imm<0 * 2048 + 256>(bufA, alo[1][0], ahi[1][0]); tr_issue_imm<1 * 2048 + 256>(bufA, alo[1][1], ahi[1][1]);
+    tr_issue_imm<2 * 2048 + 256>(bufA, alo[1][2], ahi[1][2]); tr_issue_imm<3 * 2048 + 256>(bufA, alo[1][3], ahi[1][3]);
+    tr_issue_imm<0 * 2048 + 256>(bufB, blo[1][0], bhi[1][0]); tr_issue_imm<1 * 2048 + 256>(bufB, blo[1][1], bhi[1][1]);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks == 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(alo[1][i]), "+v"(ahi[1][i]));
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) asm volatile("" : "+v"(blo[1][jj]), "+v"(bhi[1][jj]));
+      }
+      // all six operands are formed BEFORE the first matrix instruction of the k-step and a few idle cycles follow: the asm
+      // instructions get no hazard handling from hipcc, and an operand register written by a v_mov immediately in front of
+      // the matrix instruction that reads it was read stale (seen: the first tile of every k-step wrong, the others right)
+      half8 bf0 = join(blo[ks][0], bhi[ks][0]), bf1 = join(blo[ks][1], bhi[ks][1]);
+      half8 af4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af4[i] = join(alo[ks][i], ahi[ks][i]);
+      asm volatile("s_nop 7" : "+v"(bf0), "+v"(bf1), "+v"(af4[0]), "+v"(af4[1]), "+v"(af4[2]), "+v"(af4[3]));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const half8 af = af4[i];
+        mfma_agpr(acc[i][0], af, bf0);
+        mfma_agpr(acc[i][1], af, bf1);
+        if (do_bias && (i >> 1) == cq) {
+          const half2v one2 = {(_Float16)1, (_Float16)1};
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            const half2v pr = {af[e], af[e + 1]};
+            bsum[i & 1] = __builtin_amdgcn_fdot2(pr, one2, bsum[i & 1], false);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (stamp) {
+      const unsigned long long s3 = __builtin_amdgcn_s_memtime();
+      ph[0] += s1 - s0; ph[1] += s2 - s1; ph[2] += s3 - s2;
+    }
+    if (ab) { aborted = true; break; }
+  }
+  drain_matrix_pipe();
+  if (stamp && (v == 0 || v == 1) && lane == 0) {
+    unsigned* d = a.dbg + 256 * 8 * (2 + v) + (size_t)blockIdx.x * 8;
+    for (int k = 0; k < 3; ++k) d[k] = (unsigned)(ph[k] >> 4);
+    d[3] = (unsigned)(tw >> 4); d[4] = (unsigned)(tb >> 4);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  barrier_mem();
+  if (!aborted && gatew && lane < 2) st_agent(lane == 0 ? my_cons : my_prod, (unsigned)n_my);
+  if (a.dbg && gatew && lane == 0) {
+    unsigned* d = a.dbg + (size_t)blockIdx.x * 8;
+    d[0] = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_begin); d[1] = st_in[0]; d[2] = st_in[1]; d[3] = st_out[0]; d[4] = st_out[1];
+    d[5] = (unsigned)n_my; d[6] = (unsigned)l; d[7] = (unsigned)P;
+  }
+
+  // ---- partial sums -> workspace [layer l][pipeline P][tr][tc 9][reg][lane] ----
+  float* out = a.partial + ((size_t)l * a.NP + P) * (PT * (PT + 1)) * 1024;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      store_tile(acc[i][jj], out + ((size_t)(r0 + i) * (PT + 1) + (4 * j + c0 + jj)) * 1024);
+    }
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float bv = bsum[i] + __shfl_xor(bsum[i], 32);
+      if (lane < 32) out[((size_t)(r0 + 2 * cq + i) * (PT + 1) + PT) * 1024 + lane] = bv;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// in-layer stage: dW_0[J_j rows][84] and db_0[J_j] from dZ_0[J_j] (link 0, producer j) and the encoding stash
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void in_stage(const PipeArgs& a, char* smem, int P, int j, int64_t cbeg, int n_my) {
+  constexpr int PW = 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave >= 4) {      // the workgroup has eight waves for the hidden stages' sake; this light stage uses four
+    for (int it = -(NBUF - 1); it < n_my; ++it) {
+      barrier_mem();
+      if (lds_ld((unsigned)(uintptr_t)smem + NBUF * BUF_IN + 1024 + NBUF * 256 + (it & 1) * 4)) break;
+    }
+    barrier_mem();
+    return;
+  }
+  const int n_act = a.n_linear - 1, n_links = n_act - 1;
+  const StashLayout SL(PD, a.n_linear);
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  const unsigned lds_dummy = lds0 + NBUF * BUF_IN;
+  const unsigned lds_poll = lds_dummy + 1024;
+  const unsigned lds_abort = lds_poll + NBUF * 256;
+  unsigned* status = a.ctrl;
+
+  f32x16 acc[3];
+  float bsum = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) acc[c] = (f32x16){0};
+
+  const char* ring_in = a.rings + ((size_t)P * n_links + 0) * RING * SLOT;
+  unsigned* in_prod = a.ctrl + ctrl_counter_word(n_links, P, 0, j);
+  unsigned* my_cons = a.ctrl + ctrl_counter_word(n_links, P, 0, 2 + j);
+  unsigned have_in = 0;
+  unsigned st_in[2] = {0, 0};
+  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+  const size_t act_chunk = SL.chunk_bytes();
+  const unsigned laneoff = tr_lane_offset(lane);
+  const int64_t safe = cbeg < a.n_chunks_total ? cbeg : a.n_chunks_total - 1;
+
+  // 14 pieces: dZ_0 fragments 8 j + p (p < 8), encoding fragments p - 8 (8 <= p < 14); waves 2, 3 issue one surplus piece
+  auto issue_chunk = [&](int c, int buf) __attribute__((always_inline)) {
+    const bool real = c < n_my;
+    const int64_t g = real ? cbeg + c : safe;
+    const unsigned dst0 = lds0 + buf * BUF_IN;
+    const char* z = ring_in + (size_t)((real ? c : 0) % RING) * SLOT + (size_t)(8 * j) * 1024 + lane * 16;
+    const char* e = a.act_stash + (size_t)g * act_chunk + lane * 16;
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const int p = 4 * k + wave;
+      if (k < 2) dma_piece<2>(z + (size_t)p * 1024, real ? dst0 + p * 1024 : lds_dummy);
+      else {
+        const bool use = real && p < 14;
+        dma_piece<1>(e + (size_t)(p < 14 ? p - 8 : 0) * 1024, use ? dst0 + p * 1024 : lds_dummy);
+      }
+    }
+  };
+
+  bool aborted = false;
+  for (int it = -(NBUF - 1); it < n_my; ++it) {
+    const int buf = it & (NBUF - 1);
+    const int nxt = it + NBUF - 1;
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * (PW + 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * PW) : "memory");
+    if (wave == 0) {
+      bool ok = true;
+      if (it >= 0) {
+        const unsigned p0 = lds_ld(lds_poll + buf * 256);
+        if ((int)(p0 - have_in) > 0) have_in = p0;
+      }
+      if (lane == 0) {
+        if (nxt < n_my && (int)(have_in - (unsigned)(nxt + 1)) < 0) ok = spin_until(in_prod, in_prod, (unsigned)(nxt + 1), status, have_in, st_in);
+        lds_st(lds_abort + (it & 1) * 4, ok ? 0u : 1u);
+      }
+      have_in = __builtin_amdgcn_readfirstlane(have_in);
+    }
+    barrier_mem();
+    if (lds_ld(lds_abort + (it & 1) * 4)) { aborted = true; break; }
+    if (wave == 0) {
+      if (lane == 0) st_agent(my_cons, (unsigned)(it + 1 > 0 ? it + 1 : 0));
+      dma_poll(in_prod, lds_poll + (nxt & (NBUF - 1)) * 256);
+    }
+    issue_chunk(nxt, nxt & (NBUF - 1));
+    if (it < 0) continue;
+    const unsigned bufA = lds0 + buf * BUF_IN + laneoff, bufB = bufA + 8 * 1024;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half4 alo, ahi, blo[3], bhi[3];
+      tr_issue(bufA + (2 * wave) * 1024 + ks * 256, alo, ahi);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) tr_issue(bufB + (2 * c) * 1024 + ks * 256, blo[c], bhi[c]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("" : "+v"(alo), "+v"(ahi));
+#pragma unroll
+      for (int c = 0; c < 3; ++c) asm volatile("" : "+v"(blo[c]), "+v"(bhi[c]));
+      const half8 af = join(alo, ahi);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, join(blo[c], bhi[c]), acc[c], 0, 0, 0);
+      const half2v one2 = {(_Float16)1, (_Float16)1};
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const half2v pr = {af[e], af[e + 1]};
+        bsum = __builtin_amdgcn_fdot2(pr, one2, bsum, false);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  barrier_mem();
+  if (!aborted && wave == 0 && lane == 0) st_agent(my_cons, (unsigned)n_my);
+  if (a.dbg && tid == 0) {
+    unsigned* d = a.dbg + (size_t)blockIdx.x * 8;
+    d[0] = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_begin); d[1] = st_in[0]; d[2] = st_in[1]; d[3] = 0; d[4] = 0;
+    d[5] = (unsigned)n_my; d[6] = 0; d[7] = (unsigned)P;
+  }
+
+  float* out = a.partial + ((size_t)0 * a.NP + P) * (PT * (PT + 1)) * 1024;
+  const int tr = 4 * j + wave;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    store_tile(acc[c], out + ((size_t)tr * (PT + 1) + c) * 1024);
+  }
+  const float v = bsum + __shfl_xor(bsum, 32);
+  if (lane < 32) out[((size_t)tr * (PT + 1) + PT) * 1024 + lane] = v;
+}
+
+template <bool HI_ONLY>
+__global__ __launch_bounds__(WG, 1) void bwd_pipe_kernel(PipeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int n_act = a.n_linear - 1;
+  const int per_pipe = 2 * n_act;
+  const int b = blockIdx.x, x = b & 7, i = b >> 3;
+  unsigned* status = a.ctrl;
+
+  // ---- start-up: everybody resident, every class (blockIdx % 8) on one XCD ----
+  // (no static __shared__: it would shift the dynamic region off its 16-byte alignment)
+  const unsigned start_ok = (unsigned)(uintptr_t)smem + NBUF * BUF_HID + 1024 + NBUF * 256 + 32;
+  if (tid == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xf;
+    const unsigned old = __hip_atomic_fetch_or((gu32*)(a.ctrl + 8 + x), 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    (void)old;
+    __hip_atomic_fetch_add((gu32*)(a.ctrl + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool ok = true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (ld_agent(a.ctrl + 1) < gridDim.x) {
+      if (ld_agent(status) != ST_OK) { ok = false; break; }
+      if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT) { st_agent(status, ST_START_TIMEOUT); ok = false; break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (ok) {
+      const unsigned m = ld_agent(a.ctrl + 8 + x);
+      if (__builtin_popcount(m) != 1) { st_agent(status, ST_PLACEMENT); ok = false; }
+    }
+    lds_st(start_ok, ok ? 1u : 0u);
+  }
+  __syncthreads();
+  const bool ok = lds_ld(start_ok) != 0;
+
+  const int q = i / per_pipe;
+  if (q >= a.NPX) return;                       // workgroups beyond the last whole pipeline of their class
+  const int r = i % per_pipe, si = r >> 1, j = r & 1;
+  const int l = n_act - 1 - si;
+  const int P = q * 8 + x;
+  const int64_t per = (a.n_chunks_total + a.NP - 1) / a.NP;
+  const int64_t cbeg = (int64_t)P * per;
+  int64_t cend = cbeg + per;
+  if (cend > a.n_chunks_total) cend = a.n_chunks_total;
+  // a launch that failed its start-up check does no work: zero partial sums, NaN gradients via the status word
+  const int n_my = (ok && cend > cbeg) ? (int)(cend - cbeg) : 0;
+  if (l == 0) in_stage(a, smem, P, j, cbeg, n_my);
+  else if (l == n_act - 1) hidden_stage<HI_ONLY, true>(a, smem, P, l, j, cbeg, n_my);
+  else hidden_stage<HI_ONLY, false>(a, smem, P, l, j, cbeg, n_my);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// prologue: dZ of the last activation layer (-> dz_top) and dW / db of the out layer, one streaming pass over g_raw and the
+// H / cos fragments of the last activation layer
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG_PRE, 1) void bwd_prologue_kernel(PipeArgs a) {
+  constexpr int PW = 8, NO = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, h = lane >> 5;
+  const int n_act = a.n_linear - 1;
+  const StashLayout SL(PD, a.n_linear);
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  const unsigned lds_dummy = lds0 + NBUF * BUF_PRE;
+  const float gscale = sunerf_gscale(*a.g_absmax_bits);
+
+  const int64_t per = (a.n_chunks_total + gridDim.x - 1) / gridDim.x;
+  const int64_t cbeg = (int64_t)blockIdx.x * per;
+  int64_t cend = cbeg + per;
+  if (cend > a.n_chunks_total) cend = a.n_chunks_total;
+  const int n_my = cend > cbeg ? (int)(cend - cbeg) : 0;
+  const int64_t safe = cbeg < a.n_chunks_total ? cbeg : a.n_chunks_total - 1;
+
+  // W_out^T A fragments of this wave's two tiles (one k-step: rows = features 32 U + m, k = output index)
+  half8 aT[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) aT[t] = *(const half8*)(a.packedT + (size_t)(2 * wave + t) * 1024 + lane * 16);
+
+  f32x16 acc[2] = {(f32x16){0}, (f32x16){0}};
+  float bsum = 0.f;
+  const size_t act_chunk = SL.chunk_bytes();
+  const char* srcH0 = a.act_stash + SL.h_off(n_act - 1) + lane * 16;
+  const char* srcC0 = a.act_stash + SL.c_off(n_act - 1) + lane * 16;
+  const unsigned laneoff = tr_lane_offset(lane);
+  char* scratch = a.rings + (size_t)a.NP * (n_act - 1) * RING * SLOT + ((size_t)blockIdx.x * 4 + wave) * 2048;
+
+  auto issue_chunk = [&](int c, int buf) __attribute__((always_inline)) {
+    const bool real = c < n_my;
+    const int64_t g = real ? cbeg + c : safe;
+    const unsigned dst0 = lds0 + buf * BUF_PRE;
+    if (wave == 0) {
+      // g_raw of the chunk's 32 samples (2 floats each, contiguous inside a ray): lane t <- float t.  Samples past the end of
+      // the ray are not loaded (the first sample of a chunk always exists, so the instruction is always issued: the counted
+      // vmcnt waits rely on that).  A compiler-visible load here would drain the whole DMA queue with vmcnt(0) every chunk.
+      const int64_t ray = g / a.n_chunks;
+      const int c32 = (int)(g % a.n_chunks) * 32;
+      if (c32 + (lane >> 1) < a.S) dma_poll((const unsigned*)(a.g_raw + ((size_t)ray * a.S + c32) * 2 + lane), real ? dst0 + 34 * 1024 : lds_dummy);
+    }
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const int p = 4 * k + wave;
+      if (k < 4) dma_piece<1>(srcH0 + (size_t)g * act_chunk + (size_t)p * 1024, real ? dst0 + p * 1024 : lds_dummy);
+      else dma_piece<1>(srcC0 + (size_t)g * act_chunk + (size_t)(p - 16) * 1024, real ? dst0 + p * 1024 : lds_dummy);
+    }
+  };
+
+  for (int it = -(NBUF - 1); it < n_my; ++it) {
+    const int buf = it & (NBUF - 1);
+    const int nxt = it + NBUF - 1;
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NO + 2 * (PW + NO + 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NO + 2 * (PW + NO)) : "memory");
+    half8 dzo = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (it >= 0) {
+      // g_raw of this lane's sample -> B fragment of the out layer's dZ (features 0 / 1 = d loss / d raw[..., 0 / 1]) and the
+      // A-operand tile of the out layer's weight gradient (fragment-order index 16 s + 8 h + e -> s = 0, h = 0, e = 0 / 1)
+      const int64_t chunk = cbeg + it;
+      const int64_t ray = chunk / a.n_chunks;
+      const int c = (int)(chunk % a.n_chunks);
+      const int i = 32 * c + n;
+      (void)ray;
+      if (h == 0 && i < a.S) {
+        const f32x2 g = *(const f32x2*)(smem + (size_t)buf * BUF_PRE + 34 * 1024 + n * 8);
+        dzo[0] = (_Float16)(g[0] * gscale);
+        if (a.d_out > 1) dzo[1] = (_Float16)(g[1] * gscale);
+      }
+      if (wave == 0) *(half8*)(smem + (size_t)buf * BUF_PRE + 32 * 1024 + lane * 16) = dzo;
+      else if (wave == 1) *(half8*)(smem + (size_t)buf * BUF_PRE + 33 * 1024 + lane * 16) = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    barrier_mem();
+    issue_chunk(nxt, nxt & (NBUF - 1));
+    if (it < 0) {
+      const Rsrc sc = make_rsrc(scratch, 2048);
+      const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < NO; ++k) buf_store(zero, sc, (k & 1) * 1024);
+      continue;
+    }
+    const char* B = smem + (size_t)buf * BUF_PRE;
+    // ---- dZ_top tiles 2 w, 2 w + 1: (W_out^T g) * cos ----
+    const Rsrc ro = make_rsrc(a.dz_top + (size_t)(cbeg + it) * SLOT, SLOT);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int U = 2 * wave + t;
+      f32x16 d = {0};
+      d = __builtin_amdgcn_mfma_f32_32x32x16_f16(aT[t], dzo, d, 0, 0, 0);
+      const half8 c0f = *(const half8*)(B + (16 + 2 * U) * 1024 + lane * 16);
+      const half8 c1f = *(const half8*)(B + (17 + 2 * U) * 1024 + lane * 16);
+      half8 d0, d1;
+      dz_tile(d, c0f, c1f, d0, d1);
+      buf_store(d0, ro, (2 * U) * 1024);
+      buf_store(d1, ro, (2 * U + 1) * 1024);
+    }
+    // ---- out layer weight gradient: row tile 0 (outputs 0 / 1), column tiles 2 w, 2 w + 1 of H_top ----
+    const unsigned bufH = lds0 + buf * BUF_PRE + laneoff, bufA = bufH + 32 * 1024;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half4 alo, ahi, blo[2], bhi[2];
+      tr_issue(bufA + ks * 256, alo, ahi);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) tr_issue(bufH + (2 * (2 * wave + t)) * 1024 + ks * 256, blo[t], bhi[t]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("" : "+v"(alo), "+v"(ahi));
+#pragma unroll
+      for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(blo[t]), "+v"(bhi[t]));
+      const half8 af = join(alo, ahi);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, join(blo[t], bhi[t]), acc[t], 0, 0, 0);
+      if (wave == 0) {
+        const half2v one2 = {(_Float16)1, (_Float16)1};
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const half2v pr = {af[e], af[e + 1]};
+          bsum = __builtin_amdgcn_fdot2(pr, one2, bsum, false);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float* out = a.partial_out + (size_t)blockIdx.x * (PT + 1) * 1024;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    store_tile(acc[t], out + (size_t)(2 * wave + t) * 1024);
+  }
+  if (wave == 0) {
+    const float v = bsum + __shfl_xor(bsum, 32);
+    if (lane < 32) out[(size_t)PT * 1024 + lane] = v;
+  }
+}
+
+struct PipeLayout {
+  int n_act, n_links, NPX, NP, grid;
+  size_t ctrl, rings, dz_top, partial, partial_out, dbg, total;
+  PipeLayout(int64_t n_chunks_total, int n_linear, int cus) {
+    n_act = n_linear - 1;
+    n_links = n_act - 1;
+    grid = cus;
+    NPX = (cus / 8) / (2 * n_act);
+    NP = 8 * NPX;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    size_t off = 0;
+    ctrl = off; off += up(ctrl_bytes(NP, n_links));
+    rings = off; off += up((size_t)NP * n_links * RING * SLOT + (size_t)cus * 4 * 2048);
+    dz_top = off; off += up((size_t)(n_chunks_total > 0 ? n_chunks_total : 1) * SLOT);
+    partial = off; off += up((size_t)n_act * NP * PT * (PT + 1) * 1024 * sizeof(float));
+    partial_out = off; off += up((size_t)cus * (PT + 1) * 1024 * sizeof(float));
+    dbg = off; off += up((size_t)cus * 32 * sizeof(unsigned));
+    total = off;
+  }
+};
+
+bool pipe_supported(int d_filter, int n_linear, int d_out, int cus) {
+  return d_filter == PD && n_linear >= 3 && n_linear <= SUNERF_MAX_LAYERS && d_out >= 1 && d_out <= 2 && cus == 256 &&
+         2 * (n_linear - 1) <= cus / 8;
+}
+
+int device_cus() {
+  int dev = 0, cus = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  return cus;
+}
+
+}  // namespace
+
+extern "C" size_t sunerf_bwd_pipe_workspace_bytes(int64_t n_rays, int n_samples, int d_filter, int n_linear) {
+  const int cus = device_cus();
+  if (n_rays < 0 || n_samples < 2 || !pipe_supported(d_filter, n_linear, 1, cus)) return 0;
+  const int64_t n_chunks = (n_samples + 31) / 32;
+  return PipeLayout(n_rays * n_chunks, n_linear, cus).total;
+}
+
+extern "C" int sunerf_mlp_backward_pipe(int d_filter, int n_linear, int d_out, const void* packedT, const void* act_stash,
+                                        const float* g_raw, const void* g_absmax, int64_t n_rays, int n_samples,
+                                        void* workspace, size_t workspace_bytes, float* const* grad_weights_host,
+                                        float* const* grad_biases_host, int accumulate, int flags, void* stream) {
+  if (!grad_weights_host || !grad_biases_host) return SUNERF_E_BADARG;
+  if (n_rays <= 0 || n_samples < 2) return SUNERF_E_BADARG;
+  if (!packedT || !act_stash || !g_raw || !g_absmax || !workspace) return SUNERF_E_BADARG;
+  const int cus = device_cus();
+  if (!pipe_supported(d_filter, n_linear, d_out, cus)) return SUNERF_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int n_chunks = (n_samples + 31) / 32;
+  const PipeLayout L(n_rays * n_chunks, n_linear, cus);
+  if (workspace_bytes < L.total) return SUNERF_E_WORKSPACE;
+  char* ws = (char*)workspace;
+  PipeArgs a;
+  a.packedT = (const char*)packedT; a.act_stash = (const char*)act_stash; a.dz_top = ws + L.dz_top; a.rings = ws + L.rings;
+  a.ctrl = (unsigned*)(ws + L.ctrl); a.partial = (float*)(ws + L.partial); a.g_raw = g_raw;
+  a.g_absmax_bits = (const unsigned*)g_absmax; a.partial_out = (float*)(ws + L.partial_out);
+  a.n_chunks_total = n_rays * n_chunks; a.S = n_samples; a.n_chunks = n_chunks; a.n_linear = n_linear; a.d_out = d_out;
+  a.NP = L.NP; a.NPX = L.NPX; a.hi_only = flags & 1;
+  a.dbg = (flags & 2) ? (unsigned*)(ws + L.dbg) : nullptr;
+  a.xflags = flags & (4 | 8 | 16);
+  hipError_t e;
+  if ((e = hipMemsetAsync(ws + L.ctrl, 0, L.rings - L.ctrl, st)) != hipSuccess) return (int)e;
+  const size_t lds_pre = (size_t)NBUF * BUF_PRE + 1024;
+  const size_t lds_pipe = (size_t)NBUF * BUF_HID + 1024 + NBUF * 256 + 64;
+  if ((e = hipFuncSetAttribute((const void*)bwd_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pre)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)bwd_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void*)bwd_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe)) != hipSuccess) return (int)e;
+  SUNERF_CLEAR_ERROR();
+  hipLaunchKernelGGL(bwd_prologue_kernel, dim3((unsigned)cus), dim3(WG_PRE), lds_pre, st, a);
+  SUNERF_CHECK_LAUNCH();
+  if (a.hi_only) hipLaunchKernelGGL(bwd_pipe_kernel<true>, dim3((unsigned)cus), dim3(WG), lds_pipe, st, a);
+  else hipLaunchKernelGGL(bwd_pipe_kernel<false>, dim3((unsigned)cus), dim3(WG), lds_pipe, st, a);
+  SUNERF_CHECK_LAUNCH();
+  ReduceArgs r;
+  const size_t slot = (size_t)PT * (PT + 1) * 1024;
+  for (int i = 0; i < n_linear; ++i) {
+    if (!grad_weights_host[i] || !grad_biases_host[i]) return SUNERF_E_BADARG;
+    r.gW[i] = grad_weights_host[i];
+    r.gb[i] = grad_biases_host[i];
+    if (i < n_linear - 1) {
+      r.partial[i] = a.partial + (size_t)i * L.NP * slot;
+      r.split[i] = L.NP;
+      r.slot[i] = slot;
+    } else {
+      r.partial[i] = a.partial_out;
+      r.split[i] = cus;
+      r.slot[i] = (size_t)(PT + 1) * 1024;
+    }
+  }
+  r.g_absmax_bits = (const unsigned*)g_absmax; r.n_linear = n_linear; r.D = d_filter; r.d_out = d_out; r.accumulate = accumulate;
+  r.sumsq = (const float*)((const char*)packedT + sunerf_packed_mlp_t_bytes(d_filter, n_linear) - SUNERF_MAX_LAYERS * sizeof(float));
+  r.status = a.ctrl;
+  hipLaunchKernelGGL(reduce_grads_kernel, dim3(PT * (PT + 1) * 1024 / 256, n_linear), dim3(256), 0, st, r);
+  SUNERF_CHECK_LAUNCH();
+  return 0;
+}

@@ -12,14 +12,11 @@
 // contiguous slice of chunks; wave w owns the 4 x 4 tile quadrant (w >> 1, w & 1) = 256 accumulator registers.  The
 // kernel is HBM-bound (1 KiB of fragments per sample and layer against 64 MFMA-cycles), so the staging is a plain
 // register-prefetched double buffer.  Partials go to a workspace and are summed by reduce_grads_kernel.
-#include "sunerf_common.h"
-#include "../../include/sunerf_hip.h"
+#include "grad_common.h"
 
 namespace {
 
 constexpr int WG_THREADS = 256;
-
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 struct WgradArgs {
   const char* act_stash;
@@ -36,30 +33,9 @@ struct WgradArgs {
 
 __device__ __forceinline__ float gscale_from_bits(unsigned bits) { return sunerf_gscale(bits); }
 
-// transposed read of one MFMA operand (32 features x 16 samples) from a fragment pair staged in LDS: two
-// ds_read_b64_tr_b16 (4 samples each); issue-only -- the caller waits once for a whole batch of operands.
-//   frags: LDS byte address of fragment 2T (1 KiB each, fragment 2T+1 follows); ks = k-step (samples 16 ks .. 16 ks + 15)
-__device__ __forceinline__ unsigned tr_lane_offset(int lane) {
-  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-  // lanes 0-15 / 32-47: features 0-15 of the tile (fragment 2T), else 16-31 (fragment 2T+1); lanes >= 32: k 8..15
-  return (g & 1) * 1024 + ((p >> 1) * 32 + 8 * (g >> 1) + q) * 16 + (p & 1) * 8;
-}
-__device__ __forceinline__ void tr_issue(unsigned addr, half4& lo, half4& hi) {
-  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:64"
-               : "=&v"(lo), "=&v"(hi) : "v"(addr) : "memory");
-}
-__device__ __forceinline__ half8 join(half4 lo, half4 hi) {
-  half8 r;
-  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-  return r;
-}
-
 constexpr int NBUF = 4;   // LDS ring of chunk buffers (3 chunks of HBM latency cover)
 
 // KIND: 0 = in layer (X = encoding, 6 fragments), 1 = hidden layer, 2 = out layer (dZ built from g_raw)
-// tiles per side of the partial-sum workspace (bias column = index wg_tiles)
-__host__ __device__ constexpr int wg_tiles(int D) { return D / 32 > 8 ? D / 32 : 8; }
 // a workgroup covers at most 8 x 8 tiles (4 waves x 4 x 4 tiles = all 256 AGPRs): D = 512 is split over 2 x 2 workgroups
 __host__ __device__ constexpr int wg_quads(int D) { return D > 256 ? 2 : 1; }
 
@@ -254,61 +230,6 @@ __global__ __launch_bounds__(WG_THREADS, 1) void wgrad_kernel(WgradArgs a) {
   else wgrad_body<D, 1>(a, smem, layer, split, qa, qb);
 }
 
-// feature of fragment-order index f (= 16 s + 8 h + e) on the activation side / the encoding side
-__device__ __forceinline__ int frag_feature_hidden(int f) { return kmap_hidden(f >> 4, (f >> 3) & 1, f & 7); }
-__device__ __forceinline__ int frag_feature_enc(int f) { return kmap_encoding(f >> 4, (f >> 3) & 1, f & 7); }
-
-struct ReduceArgs {
-  const float* partial;
-  const unsigned* g_absmax_bits;
-  float* gW[SUNERF_MAX_LAYERS];
-  float* gb[SUNERF_MAX_LAYERS];
-  int n_linear, D, d_out, split;
-  int accumulate;     // 0: overwrite grads, 1: add to them
-  const float* sumsq; // per-layer sums of squares at the tail of the transposed image (the boosts folded into W^T), or null
-};
-
-// one thread per element of every dW / db: sums the split partials, unscales, writes nn.Linear layouts
-__global__ void reduce_grads_kernel(ReduceArgs a) {
-  const int layer = blockIdx.y;
-  const int D = a.D;
-  const int rows = (layer == a.n_linear - 1) ? a.d_out : D;
-  const int cols = (layer == 0) ? SUNERF_ENC_DIM : D;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  // enumerate in tile order so that reads of the partials are coalesced: idx = ((tr*(T+1) + tc)*16 + reg)*64 + lane
-  const int T = wg_tiles(D);
-  const int row_tiles = (layer == a.n_linear - 1) ? 1 : D / 32;
-  const int col_tiles = (layer == 0) ? SUNERF_KS0 / 2 : D / 32;
-  if (idx >= row_tiles * (T + 1) * 1024) return;
-  const int lane = idx & 63, reg = (idx >> 6) & 15, t = idx >> 10;
-  const int tr = t / (T + 1), tc = t % (T + 1);
-  if (tc != T && tc >= col_tiles) return;
-  int k = 0;
-  int fa_row = acc_row(reg, lane >> 5);
-  if (tc == T) {                                        // bias slot: 32 plain sums per row tile (reg 0, lanes 0..31)
-    if (reg != 0 || lane >= 32) return;
-    fa_row = lane;
-  } else {
-    const int fb = 32 * tc + (lane & 31);               // fragment-order index on the X side
-    k = (layer == 0) ? frag_feature_enc(fb) : frag_feature_hidden(fb);
-    if (k < 0 || k >= cols) return;
-  }
-  const int fa = 32 * tr + fa_row;                      // fragment-order index on the dZ side
-  const int j = (layer == a.n_linear - 1) ? fa : frag_feature_hidden(fa);   // out layer: feature index = output index
-  if (j >= rows) return;
-  const size_t slot = (size_t)T * (T + 1) * 1024;
-  const float* p = a.partial + (size_t)layer * a.split * slot + ((size_t)tr * (T + 1) + tc) * 1024 + reg * 64 + lane;
-  float sum = 0.f;
-  for (int s = 0; s < a.split; ++s) sum += p[(size_t)s * slot];
-  // dZ of this layer carries the boosts of every layer above it (sunerf_common.h: sunerf_bwd_boost)
-  int boost = 0;
-  if (a.sumsq)
-    for (int l = layer + 1; l < a.n_linear; ++l) boost += sunerf_bwd_boost(a.sumsq[l], D);
-  const float inv = ldexpf(sunerf_gscale_inv(*a.g_absmax_bits), -boost);
-  float* dst = (tc == T) ? a.gb[layer] + j : a.gW[layer] + (size_t)j * cols + k;
-  *dst = a.accumulate ? *dst + sum * inv : sum * inv;
-}
-
 }  // namespace
 
 extern "C" size_t sunerf_wgrad_workspace_bytes(int d_filter, int n_linear, int split) {
@@ -369,10 +290,17 @@ extern "C" int sunerf_mlp_wgrad(int d_filter, int n_linear, int d_out, const voi
     default: hipLaunchKernelGGL(wgrad_kernel<512>, dim3(grid), dim3(WG_THREADS), lds, st, a); break;
   }
   SUNERF_CHECK_LAUNCH();
-  r.partial = (const float*)workspace; r.g_absmax_bits = (const unsigned*)g_absmax; r.n_linear = n_linear; r.D = d_filter;
+  const size_t slot = (size_t)wg_tiles(d_filter) * (wg_tiles(d_filter) + 1) * 1024;
+  for (int i = 0; i < n_linear; ++i) {
+    r.partial[i] = (const float*)workspace + (size_t)i * split * slot;
+    r.split[i] = split;
+    r.slot[i] = slot;
+  }
+  r.status = nullptr;
+  r.g_absmax_bits = (const unsigned*)g_absmax; r.n_linear = n_linear; r.D = d_filter;
   // the boosts sunerf_pack_mlp_t folded into the transposed image the data gradient went through (its tail holds their source)
   r.sumsq = (const float*)((const char*)packedT + sunerf_packed_mlp_t_bytes(d_filter, n_linear) - SUNERF_MAX_LAYERS * sizeof(float));
-  r.d_out = d_out; r.split = split; r.accumulate = accumulate;
+  r.d_out = d_out; r.accumulate = accumulate;
   const unsigned tt = (unsigned)wg_tiles(d_filter);
   hipLaunchKernelGGL(reduce_grads_kernel, dim3(tt * (tt + 1) * 1024 / 256, n_linear), dim3(256), 0, st, r);
   SUNERF_CHECK_LAUNCH();

@@ -48,6 +48,11 @@ _SIGNATURES = {
                                          ctypes.c_int64, ctypes.c_int, c_void, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
                                          c_void]),
+    'sunerf_bwd_pipe_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    'sunerf_mlp_backward_pipe': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void, c_void, c_f32p, c_void,
+                                                 ctypes.c_int64, ctypes.c_int, c_void, ctypes.c_size_t,
+                                                 ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
+                                                 ctypes.c_int, c_void]),
     'sunerf_dt_integral_fwd': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, c_f32p, c_f32p, c_f32p,
                                                c_f32p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                                ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
@@ -98,7 +103,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.sunerf_abi_version() != 6:
+        if lib.sunerf_abi_version() != 7:
             raise SunerfHipError('libsunerf_hip.so ABI version mismatch')
         _lib = lib
     return _lib

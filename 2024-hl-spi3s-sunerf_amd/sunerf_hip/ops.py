@@ -423,6 +423,70 @@ def emission_integral_bwd(raw, z_vals, rays_d, g_image=None, g_weights=None, g_a
     return g_raw
 
 
+# ---- which backward runs -------------------------------------------------------------------------
+# 'pipe' (default): the layer-pipelined kernel of csrc/bwd_pipe.hip where it applies (d_filter 256, n_linear >= 3, a 256-CU
+# device), the two-kernel dgrad + wgrad elsewhere; 'classic': always the two kernels.  The pipelined launch needs all of its
+# 256 workgroups resident at once: ranks that SHARE one GPU (the CPU-rehearsal tests) must use 'classic'.
+_backward_forced = None
+_pipe_ws = {}                             # (device, stream) -> (workspace, bytes)
+_pipe_checked = {}                        # workspaces whose status word has not been looked at yet
+
+
+def backward_mode() -> str:
+    if _backward_forced is not None:
+        return _backward_forced
+    mode = os.environ.get('SUNERF_BACKWARD', 'pipe').lower()
+    if mode not in ('pipe', 'classic'):
+        raise ValueError(f"SUNERF_BACKWARD must be 'pipe' or 'classic', not {mode!r}")
+    return mode
+
+
+def _env_on(name: str) -> bool:
+    return os.environ.get(name, '0').lower() not in ('', '0', 'false', 'no', 'off')
+
+
+def _pipe_flags() -> int:
+    return (1 if _env_on('SUNERF_PIPE_HI_ONLY') else 0) | (2 if _env_on('SUNERF_PIPE_DEBUG') else 0) | (int(os.environ.get('SUNERF_PIPE_XFLAGS', '0')) & 28)
+
+
+def pipe_debug(dev=None):
+    """SUNERF_PIPE_DEBUG=1: per-workgroup counters of the last pipelined launch, (2, 256, 8) int32: [0] loop ticks (100 MHz),
+    fallback spins and their ticks on the input link, the same on the output link, chunks, layer, pipeline; [1] shader clocks / 16 of
+    wave 1 per phase of its loop (wait, barrier, DMA issue, matrix work, epilogue)."""
+    for (d, _), ws in _pipe_ws.items():
+        if dev is None or d == dev:
+            return ws[-256 * 32 * 4:].view(torch.int32).reshape(4, 256, 8).cpu()
+    return None
+
+
+def _pipe_workspace(dev, nbytes: int) -> torch.Tensor:
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _pipe_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _pipe_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _pipe_checked[key] = ws
+    return ws
+
+
+def pipe_status(raise_on_failure: bool = True) -> int:
+    """Status words of the pipelined backward launches since the last call (one 4-byte read per workspace; call it where the
+    step synchronises anyway).  Non-zero: a launch gave up (csrc/bwd_pipe.hip) -- its gradients were NaN, so the optimiser
+    skipped that step; the process switches to the two-kernel backward and, by default, says so loudly."""
+    global _backward_forced
+    worst = 0
+    for key, ws in list(_pipe_checked.items()):
+        worst = max(worst, int(ws[:4].view(torch.int32).item()))
+        del _pipe_checked[key]
+    if worst:
+        _backward_forced = 'classic'
+        if raise_on_failure:
+            raise _l.SunerfHipError(
+                f'the pipelined backward gave up (status {worst}: 1 = workgroups not co-resident, 2 = a workgroup class was '
+                'not placed on one XCD, 3 = a hand-off timed out); the step was skipped (NaN gradients) and this process now '
+                'uses the two-kernel backward (SUNERF_BACKWARD=classic selects it from the start)')
+    return worst
+
+
 def mlp_backward(packed: PackedMLP, g_raw, absmax, stash, grad_weights: Sequence[torch.Tensor],
                  grad_biases: Sequence[torch.Tensor], accumulate: bool = False):
     """dgrad + wgrad of the sine MLP from the gradient w.r.t. its raw output (N,S,2): fills / accumulates the nn.Linear
@@ -432,13 +496,18 @@ def mlp_backward(packed: PackedMLP, g_raw, absmax, stash, grad_weights: Sequence
     dev = g_raw.device
     D, nl = packed.d_filter, packed.n_linear
     stream = _stream(dev)
-    dz = torch.empty(lib.sunerf_dz_stash_bytes(n, s, D, nl), dtype=torch.uint8, device=dev)
-    _l.call(dev, 'sunerf_mlp_dgrad', _ptr(packed.transposed()), D, nl, _ptr(g_raw), _ptr(absmax), _ptr(stash),
-            _ptr(dz), n, s, stream)
-    cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    cap = int(os.environ.get('SUNERF_GRID_CAP_WGRAD', 0))        # experiment knob, see csrc/sunerf_common.h
-    split = wgrad_split(nl, cap if 0 < cap < cus else cus, D)
-    ws = torch.empty(lib.sunerf_wgrad_workspace_bytes(packed.d_filter, nl, split), dtype=torch.uint8, device=dev)
+    pipe_bytes = 0
+    if n > 0 and backward_mode() == 'pipe':
+        with torch.cuda.device(dev):
+            pipe_bytes = lib.sunerf_bwd_pipe_workspace_bytes(n, s, D, nl)     # 0: shape / device outside the pipelined kernel
+    if not pipe_bytes:
+        dz = torch.empty(lib.sunerf_dz_stash_bytes(n, s, D, nl), dtype=torch.uint8, device=dev)
+        _l.call(dev, 'sunerf_mlp_dgrad', _ptr(packed.transposed()), D, nl, _ptr(g_raw), _ptr(absmax), _ptr(stash),
+                _ptr(dz), n, s, stream)
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        cap = int(os.environ.get('SUNERF_GRID_CAP_WGRAD', 0))        # experiment knob, see csrc/sunerf_common.h
+        split = wgrad_split(nl, cap if 0 < cap < cus else cus, D)
+        ws = torch.empty(lib.sunerf_wgrad_workspace_bytes(packed.d_filter, nl, split), dtype=torch.uint8, device=dev)
     out_w, out_b = list(grad_weights), list(grad_biases)
     if packed.padded:
         # zero-padded model (PackedMLP.__init__): the kernels produce gradients of the padded shapes; the model's are their
@@ -462,8 +531,13 @@ def mlp_backward(packed: PackedMLP, g_raw, absmax, stash, grad_weights: Sequence
             raise ValueError(f'grad buffer {i} has the wrong shape / layout')
     GW = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grad_weights])
     GB = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grad_biases])
-    _l.call(dev, 'sunerf_mlp_wgrad', D, nl, packed.d_out, _ptr(packed.transposed()), _ptr(stash), _ptr(dz), _ptr(g_raw), _ptr(absmax), n, s, _ptr(ws),
-            split, GW, GB, int(kernel_accumulate), stream)
+    if pipe_bytes:
+        ws = _pipe_workspace(dev, pipe_bytes)
+        _l.call(dev, 'sunerf_mlp_backward_pipe', D, nl, packed.d_out, _ptr(packed.transposed()), _ptr(stash), _ptr(g_raw),
+                _ptr(absmax), n, s, _ptr(ws), pipe_bytes, GW, GB, int(kernel_accumulate), _pipe_flags(), stream)
+    else:
+        _l.call(dev, 'sunerf_mlp_wgrad', D, nl, packed.d_out, _ptr(packed.transposed()), _ptr(stash), _ptr(dz), _ptr(g_raw), _ptr(absmax), n, s, _ptr(ws),
+                split, GW, GB, int(kernel_accumulate), stream)
     if packed.padded:
         for gw, gb, pw, pb in zip(out_w, out_b, grad_weights, grad_biases):
             if accumulate:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUNERF_ABI_VERSION 6
+#define SUNERF_ABI_VERSION 7
 
 #define SUNERF_E_BADARG   (-1)   /* null pointer / non-positive size                               */
 #define SUNERF_E_UNSUPPORTED (-2) /* d_filter / n_layers / sample count outside the compiled set     */
@@ -176,6 +176,25 @@ int sunerf_mlp_wgrad(int d_filter, int n_linear, int d_out, const void* packedT,
                      const void* dz_stash, const float* g_raw, const void* g_absmax, int64_t n_rays, int n_samples,
                      void* workspace, int split, float* const* grad_weights_host, float* const* grad_biases_host,
                      int accumulate, void* stream);
+
+/* Layer-pipelined backward (d_filter = 256, n_linear >= 3, a 256-CU device): sunerf_mlp_dgrad + sunerf_mlp_wgrad in one
+ * pass that never writes the hidden layers' dZ to HBM (csrc/bwd_pipe.hip).  Replaces the same autograd span of
+ * sunerf/model/model.py:44-57.  A streaming prologue forms dZ of the last activation layer and the out layer's dW / db; then
+ * one persistent launch in which pairs of workgroups own one Linear layer each (its dW accumulators and W^T rows stay in
+ * registers) and hand dZ from layer to layer through the L2 of the XCD they share.
+ *   workspace: sunerf_bwd_pipe_workspace_bytes(...) bytes (0 = configuration not supported: use dgrad + wgrad); its first
+ *              4-byte word is a STATUS the launch leaves behind: 0 = done; non-zero = the launch gave up (its workgroups were
+ *              not co-resident, a class of workgroups was not placed on one XCD, or a hand-off timed out) -- the gradients
+ *              are then NaN (the optimiser's non-finite guard skips the step) and the caller should fall back to
+ *              sunerf_mlp_dgrad + sunerf_mlp_wgrad
+ *   flags    : bit 0 = single fp16 W^T in the data gradient (default: fp16 head + fp16 remainder, as sunerf_mlp_dgrad)
+ * Requires that no other kernel holds CUs of the device while it runs long enough to starve it (all 256 workgroups must
+ * become resident; every wait is bounded, so a starved launch gives up instead of hanging). */
+size_t sunerf_bwd_pipe_workspace_bytes(int64_t n_rays, int n_samples, int d_filter, int n_linear);
+int sunerf_mlp_backward_pipe(int d_filter, int n_linear, int d_out, const void* packedT, const void* act_stash,
+                             const float* g_raw, const void* g_absmax, int64_t n_rays, int n_samples, void* workspace,
+                             size_t workspace_bytes, float* const* grad_weights_host, float* const* grad_biases_host,
+                             int accumulate, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Density / temperature head (run_density_temperature.py path).
