@@ -66,8 +66,6 @@ struct PipeArgs {
   int n_linear, d_out;
   int NP, NPX;              // pipelines in all / per XCD class
   int hi_only;
-  int xflags;               // timing experiments (results are garbage): 4 = no matrix work, 8 = H / cos always from one chunk (L2),
-                            // 16 = no hand-off (every stage reads dz_top, nobody waits)
   unsigned* dbg;            // optional [workgroup][8]: loop ticks, fallback spins / ticks of the input and output link, chunks, layer, pipeline
 };
 
@@ -917,20 +915,28 @@ extern "C" int sunerf_mlp_backward_pipe(int d_filter, int n_linear, int d_out, c
   a.n_chunks_total = n_rays * n_chunks; a.S = n_samples; a.n_chunks = n_chunks; a.n_linear = n_linear; a.d_out = d_out;
   a.NP = L.NP; a.NPX = L.NPX; a.hi_only = flags & 1;
   a.dbg = (flags & 2) ? (unsigned*)(ws + L.dbg) : nullptr;
-  a.xflags = flags & (4 | 8 | 16);
   hipError_t e;
-  if ((e = hipMemsetAsync(ws + L.ctrl, 0, L.rings - L.ctrl, st)) != hipSuccess) return (int)e;
+  // flags 0x10 / 0x20 / 0x40: run ONLY the prologue / the pipelined kernel / the reduction (a caller that wants events between
+  // the three launches -- bench.py's roofline line -- makes three calls); none of them set: all three
+  const int only = flags & 0x70;
+  const bool do_pre = !only || (only & 0x10), do_pipe = !only || (only & 0x20), do_red = !only || (only & 0x40);
+  if (do_pre && (e = hipMemsetAsync(ws + L.ctrl, 0, L.rings - L.ctrl, st)) != hipSuccess) return (int)e;
   const size_t lds_pre = (size_t)NBUF * BUF_PRE + 1024;
   const size_t lds_pipe = (size_t)NBUF * BUF_HID + 1024 + NBUF * 256 + 64;
   if ((e = hipFuncSetAttribute((const void*)bwd_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pre)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)bwd_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)bwd_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe)) != hipSuccess) return (int)e;
   SUNERF_CLEAR_ERROR();
-  hipLaunchKernelGGL(bwd_prologue_kernel, dim3((unsigned)cus), dim3(WG_PRE), lds_pre, st, a);
-  SUNERF_CHECK_LAUNCH();
-  if (a.hi_only) hipLaunchKernelGGL(bwd_pipe_kernel<true>, dim3((unsigned)cus), dim3(WG), lds_pipe, st, a);
-  else hipLaunchKernelGGL(bwd_pipe_kernel<false>, dim3((unsigned)cus), dim3(WG), lds_pipe, st, a);
-  SUNERF_CHECK_LAUNCH();
+  if (do_pre) {
+    hipLaunchKernelGGL(bwd_prologue_kernel, dim3((unsigned)cus), dim3(WG_PRE), lds_pre, st, a);
+    SUNERF_CHECK_LAUNCH();
+  }
+  if (do_pipe) {
+    if (a.hi_only) hipLaunchKernelGGL(bwd_pipe_kernel<true>, dim3((unsigned)cus), dim3(WG), lds_pipe, st, a);
+    else hipLaunchKernelGGL(bwd_pipe_kernel<false>, dim3((unsigned)cus), dim3(WG), lds_pipe, st, a);
+    SUNERF_CHECK_LAUNCH();
+  }
+  if (!do_red) return 0;
   ReduceArgs r;
   const size_t slot = (size_t)PT * (PT + 1) * 1024;
   for (int i = 0; i < n_linear; ++i) {

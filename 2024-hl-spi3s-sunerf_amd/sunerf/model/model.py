@@ -2,12 +2,15 @@
 (state-dict keys ``in_layer.0.freq_bands``, ``in_layer.1.{weight,bias}``, ``layers.{i}.{weight,bias}``,
 ``out_layer.{weight,bias}``) and default ``nn.Linear`` initialisation.  The arithmetic is done by the fused HIP
 kernels on a packed fp16 hi/lo image of these parameters (``sunerf_hip.ops.PackedMLP``)."""
+import threading
 from typing import Tuple
 
 import torch
 from torch import nn
 
 from sunerf_hip import ops
+
+_PACK_LOCK = threading.RLock()      # serialises (re)building the packed-weights caches (NeRF.packed)
 
 
 class Sine(nn.Module):
@@ -99,14 +102,18 @@ class NeRF(nn.Module):
         (optimizer step, load_state_dict) or moved."""
         lin = self.linears()
         key = tuple((p.data_ptr(), p._version) for l in lin for p in (l.weight, l.bias))
-        if self._packed is None or key != self._packed_key:
-            ws, bs = [l.weight for l in lin], [l.bias for l in lin]
-            if self._packed is None or self._packed.device != ws[0].device:
-                self._packed = ops.PackedMLP(ws, bs)
-            else:
-                self._packed.repack(ws, bs)
-            self._packed_key = key
-        return self._packed
+        # evaluation/loader.py:226-229 submits ray batches of one frame to a ThreadPoolExecutor: the cache is (re)built by one
+        # thread at a time
+        with _PACK_LOCK:
+            if self._packed is None or key != self._packed_key:
+                ws, bs = [l.weight for l in lin], [l.bias for l in lin]
+                if self._packed is None or self._packed.device != ws[0].device:
+                    self._packed = ops.PackedMLP(ws, bs)
+                else:
+                    with self._packed._lock:
+                        self._packed.repack(ws, bs)
+                self._packed_key = key
+            return self._packed
 
     def __getstate__(self):  # the packed image is a cache, not state (save_state pickles the module, sunerf.py:62-74)
         st = self.__dict__.copy()

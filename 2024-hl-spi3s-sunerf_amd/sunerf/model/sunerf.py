@@ -14,7 +14,7 @@ from sunerf.rendering.base_tracing import SuNeRFRendering
 from sunerf.rendering.emission import EmissionRadiativeTransfer
 from sunerf.rendering.density_temperature import DensityTemperatureRadiativeTransfer
 from sunerf.train.scaling import ImageAsinhScaling
-from sunerf_hip.train import ClipAdam, training_loss
+from sunerf_hip.train import ClipAdam, env_flag, training_loss
 
 try:  # pragma: no cover - depends on the environment
     from pytorch_lightning import LightningModule
@@ -74,6 +74,16 @@ class BaseSuNeRFModule(LightningModule):
             assert float(count) == 0, '! [Numerical Alert] an output contains NaN or Inf.'
 
     def on_train_batch_end(self, *args, **kwargs):
+        # Under data parallelism the reference's NaN / Inf assert (sunerf.py:105-107) is taken HERE, after the optimiser step, on
+        # the count the gradient all-reduce has summed over the ranks -- by every driver that ends a batch through this hook
+        # (Lightning's closure-driven automatic optimisation as well as fit_steps below); _finish_step cannot do it before the
+        # step without leaving the other ranks alone in the collective.
+        optimizer = getattr(self, 'optimizer', None)
+        if self.strict_finite_check and _data_parallel() and optimizer is not None:
+            self.check_finite(optimizer)
+        if self.strict_finite_check:
+            from sunerf_hip import ops as _ops
+            _ops.pipe_status()          # a pipelined backward launch that gave up (csrc/bwd_pipe.hip) is reported, not hidden
         if self.scheduler.get_last_lr()[0] > 5e-5:
             self.scheduler.step()
         self.log('Learning Rate', self.scheduler.get_last_lr()[0])
@@ -228,7 +238,10 @@ def fit_steps(module: BaseSuNeRFModule, batches, gradient_clip_val=0.5):
     (run_emission.py:65-75): backward, clip_grad_norm_(0.5), Adam step, on_train_batch_end."""
     (optimizer,), _ = module.configure_optimizers()
     optimizer.max_norm = gradient_clip_val          # clip fused into the optimiser step (norm and coefficient stay on device)
-    optimizer.overlap = True                        # one backward per model and step here: reduce the fine model's slice early
+    # Early all-reduce of the fine model's slice while the coarse backward still runs: one backward per model and step here, so
+    # it is legal -- but it has only ever run with RCCL at world size 1 (no multi-GPU lease so far), so it stays opt-in
+    # (SUNERF_OVERLAP=1) until a 2..8-GPU record exists; bench.py follows the same switch.
+    optimizer.overlap = env_flag('SUNERF_OVERLAP')
     losses = []
     for i, batch in enumerate(batches):
         optimizer.zero_grad()
@@ -236,8 +249,6 @@ def fit_steps(module: BaseSuNeRFModule, batches, gradient_clip_val=0.5):
         loss.backward()
         stats = getattr(module, 'last_stats', None)
         optimizer.step(skip_if_positive=None if stats is None else stats[5:6])
-        if module.strict_finite_check and _data_parallel():
-            module.check_finite(optimizer)
-        module.on_train_batch_end()
+        module.on_train_batch_end()     # (takes the all-rank finite check under data parallelism)
         losses.append(loss.detach())
     return losses

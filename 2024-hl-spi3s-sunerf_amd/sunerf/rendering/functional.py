@@ -2,6 +2,7 @@
 import torch
 
 from sunerf_hip import ops
+from sunerf_hip.train import bucket_of
 
 
 class _MlpOnPoints(torch.autograd.Function):
@@ -74,12 +75,16 @@ def _grad_targets(params):
 def _scalar_head_slice(scalars):
     """The slice of a flat gradient bucket that the given 0-d parameters occupy back to back (``ClipAdam`` tags every parameter with
     ``(owner, offset, numel)``), or None: lets eight scalar gradients be accumulated with one launch instead of eight."""
-    tags = [getattr(p, '_sunerf_bucket', None) for p in scalars]
+    tags = [bucket_of(p) for p in scalars]
     if any(t is None for t in tags):
         return None
     owner, first = tags[0][0], tags[0][1]
-    for i, (o, off, k) in enumerate(tags):
+    for i, (p, (o, off, k)) in enumerate(zip(scalars, tags)):
         if o is not owner or off != first + i or k != 1:
+            return None
+        # the parameter's .grad must still BE its slot of the bucket: a replaced / cleared .grad is copied over (or zeroed
+        # into) the slot by the optimiser's step, which would lose what is added here
+        if not p.requires_grad or p.grad is None or p.grad.data_ptr() != owner.flat_grads[off:off + 1].data_ptr():
             return None
     return owner.flat_grads[first:first + len(tags)]
 
@@ -87,7 +92,7 @@ def _scalar_head_slice(scalars):
 def _announce(params):
     """The gradients of ``params`` are final in their flat bucket: let its owner start the all-reduce of that slice while the
     other model's backward still runs (``ClipAdam(overlap=True)``)."""
-    owner = getattr(params[0], '_sunerf_bucket', None)
+    owner = bucket_of(params[0])
     if owner is not None:
         owner[0].segment_ready(params)
 
@@ -318,7 +323,9 @@ class _DtPass(torch.autograd.Function):
                                                         g_image.contiguous(), g_reg)
         la_slice = _scalar_head_slice(ctx.scalar_params[:-1])
         vol_c_param = ctx.scalar_params[-1]
-        if la_slice is not None and getattr(vol_c_param, '_sunerf_bucket', None) is not None and vol_c_param.grad is not None:
+        vc_tag = bucket_of(vol_c_param)
+        if (la_slice is not None and vc_tag is not None and vol_c_param.requires_grad and vol_c_param.grad is not None
+                and vol_c_param.grad.data_ptr() == vc_tag[0].flat_grads[vc_tag[1]:vc_tag[1] + 1].data_ptr()):
             # the seven absorption scalars sit back to back in the optimiser's flat gradient buffer (the volumetric constant, a
             # direct parameter of the module, elsewhere in it): two adds instead of eight AccumulateGrad launches
             la_slice.add_(g_la)

@@ -5,6 +5,7 @@ kernels of ``csrc/``.
 """
 import ctypes
 import os
+import threading
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -32,6 +33,12 @@ PRECISION_NAMES = {PRECISION_FAST: 'fast', PRECISION_EXACT: 'exact', PRECISION_H
 PROBE_EVERY = 64
 PROBE_RAYS = 144
 PROBE_LIMIT = 0.5
+# The FIRST probe of an image is read at once (one 4-byte device -> host copy: nothing is known about the network yet); later
+# re-probes are ASYNCHRONOUS: the measured units go to a pinned host word behind an event and the decision is taken by the first
+# render call that finds the event complete -- the training step never waits for a probe.  Under a process group the units are
+# MAX-all-reduced first, so every rank takes the same arithmetic at the same parameter version (equal step times, no rank-dependent
+# forward).
+PROBE_ASYNC = True
 
 
 def default_precision(d_filter: int) -> int:
@@ -95,6 +102,10 @@ class PackedMLP:
         self.probe_due = self.auto
         self.last_probe = None            # gate units measured by the last probe (AUTO only)
         self._versions_since_probe = 0
+        self._pending_probe = None        # (pinned host word, event, sensitivity) of a probe whose result has not been read yet
+        # evaluation/loader.py:226-229 calls the renderer from a ThreadPoolExecutor: (re)packing, probing and the buffer swap of
+        # a mode change are serialised; a render call works on the (buffer, precision) pair it read under the lock
+        self._lock = threading.RLock()
         self.d_out = int(weights[-1].shape[0])
         lib = _l.load()
         nbytes = lib.sunerf_packed_mlp_bytes(self.d_filter, self.n_linear)
@@ -144,6 +155,7 @@ class PackedMLP:
                 _ptr(self.buffer), _stream(self.device))
         self._keepalive = (ws, bs)   # until the pack kernel has run on the stream
         self._t_valid = False
+        self._version = getattr(self, '_version', 0) + 1
         if self.auto:
             self._versions_since_probe += 1
             if self._versions_since_probe >= PROBE_EVERY:
@@ -176,6 +188,7 @@ class PackedMLP:
             self._alt_buffer = torch.empty_like(self.buffer)
         other = PRECISION_EXACT if self.precision == PRECISION_FAST else PRECISION_FAST
         self._pack_into(self._alt_buffer, other)
+        self._alt_version = self._version
         views = {self.precision: self.buffer, other: self._alt_buffer}
         outs = {}
         for mode, buf in views.items():
@@ -183,21 +196,54 @@ class PackedMLP:
             shadow.__dict__.update(self.__dict__)
             shadow.buffer, shadow.precision, shadow.auto = buf, mode, False
             outs[mode] = emission_render_fwd(shadow, rays_o, rays_d, times, z_vals, reg_radius, want_epilogues=True)
-        units = torch.zeros((), dtype=torch.float32, device=self.device)
+        units = torch.zeros(1, dtype=torch.float32, device=self.device)
         for k in ('image', 'height_map', 'absorption_map'):
             f, e = outs[PRECISION_FAST][k].reshape(-1), outs[PRECISION_EXACT][k].reshape(-1)
             # absorption_map = sum(1 - a): the reference forms 1 - a in fp32, i.e. with 2^-24 absolute noise per sample
             floor = z_vals.shape[1] * 6e-8 if k == 'absorption_map' else 0.0
             units = torch.maximum(units, ((f - e).abs() / (1e-4 * e.abs() + 1e-6 * e.abs().max() + floor)).max())
-        units = float(units.item()) * float(sensitivity)
-        if not (units == units):            # NaN: non-finite outputs in either mode -- leave the decision to the finite check
-            units = float('inf')
+        units = torch.nan_to_num(units, nan=float('inf'))      # NaN: non-finite outputs in either mode -> EXACT; the finite check reports them
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(units, op=dist.ReduceOp.MAX)       # every rank probes at the same parameter version: one decision
+        host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+        host.copy_(units, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record(torch.cuda.current_stream(self.device))
+        first = self.last_probe is None
+        self._pending_probe = (host, event, float(sensitivity))
+        self._apply_probe(block=first or not PROBE_ASYNC)
+        return self.last_probe
+
+    def _apply_probe(self, block: bool = False) -> None:
+        """Takes the decision of a finished probe (``block``: waits for it)."""
+        pending = self._pending_probe
+        if pending is None:
+            return
+        host, event, sensitivity = pending
+        if block:
+            event.synchronize()
+        elif not event.query():
+            return
+        self._pending_probe = None
+        units = float(host[0]) * sensitivity
         self.last_probe = units
         want = PRECISION_FAST if units <= PROBE_LIMIT else PRECISION_EXACT
         if want != self.precision:
-            self.buffer, self._alt_buffer = self._alt_buffer, self.buffer
-            self.precision = want
-        return units
+            # (the image of the other mode was packed by the probe from the weights of ITS parameter version; a newer
+            # version re-packs the active buffer anyway, in the mode chosen here)
+            if getattr(self, '_alt_version', None) == self._version:
+                self.buffer, self._alt_buffer = self._alt_buffer, self.buffer
+                self.precision = want
+            else:
+                self.precision = want
+                self._pack_into(self.buffer, want)
+
+    def wait_probe(self) -> Optional[float]:
+        """Blocks until a probe in flight has been read and its decision taken; returns the last measured gate units."""
+        with self._lock:
+            self._apply_probe(block=True)
+            return self.last_probe
 
     def transposed(self) -> torch.Tensor:
         """fp16 W^T image consumed by sunerf_mlp_dgrad (packed lazily, once per parameter version)."""
@@ -245,8 +291,11 @@ def emission_render_fwd(packed: PackedMLP, rays_o, rays_d, times, z_vals, reg_ra
     z_vals = _dev(z_vals, 'z_vals', (n, s))
     if packed.device != dev:
         raise _l.SunerfHipError('packed weights and rays are on different devices')
-    if packed.auto and packed.probe_due:
-        packed.probe(rays_o, rays_d, times, z_vals, reg_radius, probe_sensitivity)
+    with packed._lock:
+        packed._apply_probe()
+        if packed.auto and packed.probe_due:
+            packed.probe(rays_o, rays_d, times, z_vals, reg_radius, probe_sensitivity)
+        weights_image, precision = packed.buffer, packed.precision        # this call's image, whatever other threads decide next
     f32 = dict(dtype=torch.float32, device=dev)
     out = {'image': torch.empty(n, 1, **f32), 'weights': torch.empty(n, s, **f32),
            'absorption': torch.empty(n, s, **f32)}
@@ -269,8 +318,8 @@ def emission_render_fwd(packed: PackedMLP, rays_o, rays_d, times, z_vals, reg_ra
     hm = am = reg = None
     if want_epilogues:
         hm, am, reg = torch.empty(n, **f32), torch.empty(n, **f32), torch.empty(n, s, **f32)
-    _l.call(dev, 'sunerf_emission_render_fwd', _ptr(packed.buffer), packed.d_filter, packed.n_linear,
-            packed.precision, _ptr(rays_o), _ptr(rays_d), _ptr(times), _ptr(z_vals), n, s, _ptr(out['image']),
+    _l.call(dev, 'sunerf_emission_render_fwd', _ptr(weights_image), packed.d_filter, packed.n_linear,
+            precision, _ptr(rays_o), _ptr(rays_d), _ptr(times), _ptr(z_vals), n, s, _ptr(out['image']),
             _ptr(out['weights']), _ptr(out['absorption']), _ptr(raw), _ptr(hm), _ptr(am), _ptr(reg),
             float(reg_radius), _ptr(stash), _ptr(ws), ws_bytes, _stream(dev))
     if want_raw:
@@ -292,12 +341,15 @@ def mlp_points_fwd(packed: PackedMLP, points: torch.Tensor, training: bool = Fal
     points = _dev(points, 'points', (m, 4))
     if packed.device != dev:
         raise _l.SunerfHipError('packed weights and points are on different devices')
-    if packed.auto and packed.probe_due and m > 0:
-        # the measured choice of the arithmetic (AUTO) needs rays: PROBE_RAYS of the points as two-sample rays o = 0, d = xyz, z = 1
-        k = min(PROBE_RAYS, m)
-        idx = torch.linspace(0, m - 1, k, device=dev).long()
-        sel = points[idx]
-        packed.probe(torch.zeros(k, 3, device=dev), sel[:, :3].contiguous(), sel[:, 3].contiguous(), torch.ones(k, 2, device=dev), 0.0)
+    with packed._lock:
+        packed._apply_probe()
+        if packed.auto and packed.probe_due and m > 0:
+            # the measured choice of the arithmetic (AUTO) needs rays: PROBE_RAYS of the points as two-sample rays o = 0, d = xyz, z = 1
+            k = min(PROBE_RAYS, m)
+            idx = torch.linspace(0, m - 1, k, device=dev).long()
+            sel = points[idx]
+            packed.probe(torch.zeros(k, 3, device=dev), sel[:, :3].contiguous(), sel[:, 3].contiguous(), torch.ones(k, 2, device=dev), 0.0)
+        weights_image, precision = packed.buffer, packed.precision
     m_pad = (m + 31) // 32 * 32
     if m_pad != m:
         points = torch.cat([points, points.new_zeros(m_pad - m, 4)])
@@ -314,7 +366,7 @@ def mlp_points_fwd(packed: PackedMLP, points: torch.Tensor, training: bool = Fal
     stash = None
     if training:
         stash = torch.empty(lib.sunerf_act_stash_bytes(m_pad // 32, 32, packed.d_filter, packed.n_linear), dtype=torch.uint8, device=dev)
-    _l.call(dev, 'sunerf_mlp_points_fwd', _ptr(packed.buffer), packed.d_filter, packed.n_linear, packed.precision, _ptr(points),
+    _l.call(dev, 'sunerf_mlp_points_fwd', _ptr(weights_image), packed.d_filter, packed.n_linear, precision, _ptr(points),
             m_pad, _ptr(raw), _ptr(stash), _ptr(ws), ws_bytes, _stream(dev))
     out = {'raw': raw[:m], 'n_padded': m_pad}
     if training:
@@ -428,6 +480,7 @@ def emission_integral_bwd(raw, z_vals, rays_d, g_image=None, g_weights=None, g_a
 # device), the two-kernel dgrad + wgrad elsewhere; 'classic': always the two kernels.  The pipelined launch needs all of its
 # 256 workgroups resident at once: ranks that SHARE one GPU (the CPU-rehearsal tests) must use 'classic'.
 _backward_forced = None
+pipe_kernel_events = None                 # a list: mlp_backward appends (begin, end) events around every pipelined-kernel launch
 _pipe_ws = {}                             # (device, stream) -> (workspace, bytes)
 _pipe_checked = {}                        # workspaces whose status word has not been looked at yet
 
@@ -446,7 +499,7 @@ def _env_on(name: str) -> bool:
 
 
 def _pipe_flags() -> int:
-    return (1 if _env_on('SUNERF_PIPE_HI_ONLY') else 0) | (2 if _env_on('SUNERF_PIPE_DEBUG') else 0) | (int(os.environ.get('SUNERF_PIPE_XFLAGS', '0')) & 28)
+    return (1 if _env_on('SUNERF_PIPE_HI_ONLY') else 0) | (2 if _env_on('SUNERF_PIPE_DEBUG') else 0)
 
 
 def pipe_debug(dev=None):
@@ -533,8 +586,20 @@ def mlp_backward(packed: PackedMLP, g_raw, absmax, stash, grad_weights: Sequence
     GB = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grad_biases])
     if pipe_bytes:
         ws = _pipe_workspace(dev, pipe_bytes)
-        _l.call(dev, 'sunerf_mlp_backward_pipe', D, nl, packed.d_out, _ptr(packed.transposed()), _ptr(stash), _ptr(g_raw),
-                _ptr(absmax), n, s, _ptr(ws), pipe_bytes, GW, GB, int(kernel_accumulate), _pipe_flags(), stream)
+        pargs = (D, nl, packed.d_out, _ptr(packed.transposed()), _ptr(stash), _ptr(g_raw), _ptr(absmax), n, s, _ptr(ws),
+                 pipe_bytes, GW, GB, int(kernel_accumulate))
+        if pipe_kernel_events is None:
+            _l.call(dev, 'sunerf_mlp_backward_pipe', *pargs, _pipe_flags(), stream)
+        else:
+            # bench.py's roofline line: the three launches (prologue, pipelined kernel, reduction) as three calls with HIP
+            # events on the launch stream around the middle one
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            _l.call(dev, 'sunerf_mlp_backward_pipe', *pargs, _pipe_flags() | 0x10, stream)
+            e0.record()
+            _l.call(dev, 'sunerf_mlp_backward_pipe', *pargs, _pipe_flags() | 0x20, stream)
+            e1.record()
+            _l.call(dev, 'sunerf_mlp_backward_pipe', *pargs, _pipe_flags() | 0x40, stream)
+            pipe_kernel_events.append((e0, e1))
     else:
         _l.call(dev, 'sunerf_mlp_wgrad', D, nl, packed.d_out, _ptr(packed.transposed()), _ptr(stash), _ptr(dz), _ptr(g_raw), _ptr(absmax), n, s, _ptr(ws),
                 split, GW, GB, int(kernel_accumulate), stream)

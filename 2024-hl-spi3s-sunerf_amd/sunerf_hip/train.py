@@ -7,16 +7,40 @@
 """
 import ctypes
 import os
+import weakref
 from typing import Dict, Iterable, Optional, Sequence
 
 import torch
 import torch.distributed as dist
+from torch.utils.weak import WeakIdKeyDictionary
 
 from . import lib as _l
 from .ops import _dev, _ptr, _stream
 
 STAT_KEYS = ('loss', 'coarse', 'fine', 'regularization', 'psnr', 'non_finite')
 _ws = {}      # (device, stream) -> zero-initialised reduction workspace
+
+# Which flat bucket a parameter's gradient lives in: parameter -> (weak reference to the owning ClipAdam, offset, numel).  Kept
+# HERE and not as an attribute of the nn.Parameter: torch pickles Parameter attributes, so a tag on the parameter would put the
+# optimiser (its class name and both moment buffers) into every .snf written after configure_optimizers() -- a file the
+# reference environment could then no longer unpickle -- and into every copy.deepcopy of the module.
+_BUCKETS = WeakIdKeyDictionary()      # keyed by identity: Tensor.__eq__ is element-wise
+
+
+def bucket_of(param):
+    """(owner ClipAdam, offset, numel) of a parameter whose gradient is a view of a live optimiser's flat bucket, else None."""
+    tag = _BUCKETS.get(param)
+    if tag is None:
+        return None
+    owner = tag[0]()
+    if owner is None:
+        return None
+    return owner, tag[1], tag[2]
+
+
+def env_flag(name: str) -> bool:
+    """An environment switch: unset, '', '0', 'false', 'no', 'off' are OFF."""
+    return os.environ.get(name, '').strip().lower() not in ('', '0', 'false', 'no', 'off')
 
 
 def remaining_slices(done, total):
@@ -159,7 +183,7 @@ class ClipAdam(torch.optim.Optimizer):
             self._grad_views.append(gv)
             self.state[p] = {'step': torch.tensor(0.), 'exp_avg': self.exp_avg[off:off + k].view_as(p),
                              'exp_avg_sq': self.exp_avg_sq[off:off + k].view_as(p)}
-            p._sunerf_bucket = (self, off, k)      # lets the backward node announce a finished slice (segment_ready)
+            _BUCKETS[p] = (weakref.ref(self), off, k)      # lets the backward node announce a finished slice (segment_ready)
             off += k
 
     @property
@@ -186,14 +210,26 @@ class ClipAdam(torch.optim.Optimizer):
         """Called by a backward node whose kernels have accumulated the FINAL gradients of ``params`` into the bucket: starts
         the all-reduce of that slice right away (``overlap=True`` and a process group; no-op otherwise).  The collective is
         ordered behind the gradient kernels on the current stream and runs beside whatever is launched next."""
-        if not self.overlap or not self._world() or os.environ.get('SUNERF_NO_OVERLAP'):      # (the env switch: rehearsals / A-B runs)
+        if not self.overlap or not self._world() or env_flag('SUNERF_NO_OVERLAP'):      # (the env switch: rehearsals / A-B runs)
             return
-        spans = sorted(p._sunerf_bucket[1:] for p in params)
+        tags = [bucket_of(p) for p in params]
+        if any(t is None or t[0] is not self for t in tags):
+            return        # not (all) this optimiser's parameters: step() reduces them
+        for p, (_, off, k) in zip(params, tags):
+            # the kernels must have written into the bucket itself: a .grad that autograd (or the caller) replaced is copied
+            # into the bucket by step() -- AFTER an early all-reduce of this slice it would overwrite the reduced values
+            if p.grad is None or p.grad.data_ptr() != self.flat_grads[off:off + k].data_ptr():
+                return
+        spans = sorted(t[1:] for t in tags)
         lo, hi = spans[0][0], spans[-1][0] + spans[-1][1]
-        contiguous = sum(k for _, k in spans) == hi - lo
-        clash = any(a < hi and lo < b for a, b, _ in self._early)
-        if not contiguous or clash:
-            return        # not one slice of the bucket, or overlapping an earlier one: leave it to step()
+        if sum(k for _, k in spans) != hi - lo:
+            return        # not one contiguous slice of the bucket: leave it to step()
+        if any(a < hi and lo < b for a, b, _ in self._early):
+            # a SECOND backward contribution to a slice that has already been all-reduced (gradient accumulation over
+            # micro-batches, a model used twice in one step): step() only reduces what was not sent early, so the replicas
+            # would silently diverge.  overlap=True promises exactly one backward per model and step.
+            raise RuntimeError('ClipAdam(overlap=True): a slice of the gradient bucket received a second backward contribution '
+                               'after its all-reduce had started; use overlap=False with gradient accumulation / shared models')
         self._early.append((lo, hi, dist.all_reduce(self.bucket[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
     def _collect(self):

@@ -91,12 +91,12 @@ def cpu_baseline(res, samples, mode, seconds_budget=20.0):
 
 
 
-def two_pass_rate(dev, world, rays_o, rays_d, times, target, batch, samples, steps=3, warmup=1, density_temperature=False):
+def two_pass_rate(dev, world, rays_o, rays_d, times, target, batch, samples, steps=10, warmup=2, density_temperature=False):
     """Reference-shaped training step beside the single-pass headline: StratifiedSampler (S/2 jittered
     samples) -> coarse pass -> HierarchicalSampler (S/2 more) -> fine pass over S samples -> loss on both images ->
     backward through both models -> all-reduce + clip + Adam.  MLP evaluations per ray: S/2 + S."""
     from sunerf.rendering.emission import EmissionRadiativeTransfer
-    from sunerf_hip.train import ClipAdam, training_loss
+    from sunerf_hip.train import ClipAdam, env_flag, training_loss
     torch.manual_seed(7)
     cfg = dict(Rs_per_ds=1.0, sampling_config={'type': 'stratified', 'n_samples': samples // 2},
                hierarchical_sampling_config={'type': 'hierarchical', 'n_samples': samples // 2},
@@ -116,11 +116,10 @@ def two_pass_rate(dev, world, rays_o, rays_d, times, target, batch, samples, ste
         target = torch.rand(target.shape[0], 7, generator=torch.Generator().manual_seed(1)).to(dev)
     else:
         rendering = EmissionRadiativeTransfer(**cfg).to(dev)
-    # overlap (the fine model's slice of the bucket all-reduced while the coarse model's backward runs) is what
-    # `fit_steps` uses; in this SUB-line of a driver-run record it is opt-in (SUNERF_BENCH_OVERLAP=1): the early collectives have
-    # run with RCCL at world size 1 and with gloo at 2 - 3 ranks only, a 4-rank gloo rehearsal on ONE card took seconds per step in
-    # them, and a stall here would cost the whole N-GPU record for a 2 MB all-reduce's worth of overlap
-    opt = ClipAdam(rendering.parameters(), lr=1e-4, max_norm=0.5, overlap=bool(os.environ.get('SUNERF_BENCH_OVERLAP')))
+    # overlap (the fine model's slice of the bucket all-reduced while the coarse model's backward runs): the SAME
+    # switch and default as the product's fit_steps (sunerf/model/sunerf.py) -- off unless SUNERF_OVERLAP=1, until a 2..8-GPU
+    # RCCL record of the early collectives exists -- so this line measures what the product does
+    opt = ClipAdam(rendering.parameters(), lr=1e-4, max_norm=0.5, overlap=env_flag('SUNERF_OVERLAP'))
     n_batches = max(1, rays_o.shape[0] // batch)
 
     def step(i):
@@ -175,6 +174,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-half', action='store_true', help='skip BASELINE config 3 (the same step with single fp16 MFMA operands in '
                                                            'the forward, reported under "half_precision", never as the headline)')
+    ap.add_argument('--no-exact', action='store_true', help='skip the sub-line in the unconditional EXACT arithmetic')
     ap.add_argument('--no-two-pass', action='store_true', help='skip the reference-shaped two-pass figure (train mode)')
     ap.add_argument('--no-small-batch', action='store_true', help="skip the figure at the reference's own batch of 3072 rays")
     ap.add_argument('--no-dt', action='store_true', help='skip BASELINE config 5: density-temperature head, two-pass, 128 + 256 '
@@ -243,6 +243,7 @@ def main():
         render_events.append((e0, e1))
         return out
     ops.emission_render_fwd = timed_render
+    bwd_events = []        # (begin, end) around every launch of the pipelined backward kernel (ops.mlp_backward), timed region only
 
     def timed_loop(step, steps, warmup):
         """``warmup`` untimed steps, then exactly ``steps`` steps between two barrier + synchronize pairs; max over ranks."""
@@ -310,15 +311,22 @@ def main():
     # ---- the headline: W warm-up steps, exactly K timed steps ----
     for i in range(args.warmup):
         step(i)
+    if getattr(model.packed(), 'auto', False):
+        model.packed().wait_probe()          # the AUTO probe of the warm-up is read outside the timed region
     barrier()
     recording['on'] = True
+    ops.pipe_kernel_events = bwd_events
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
     recording['on'] = False
+    ops.pipe_kernel_events = None
     render_ms = sum(a.elapsed_time(b) for a, b in render_events) / max(1, len(render_events))
+    bwd_ms = sum(a.elapsed_time(b) for a, b in bwd_events) / len(bwd_events) if bwd_events else None
+    backward_used = 'pipe' if bwd_events else ('classic' if args.mode == 'train' else None)
+    pipe_failed = ops.pipe_status(raise_on_failure=False) if args.mode == 'train' else 0
     assert torch.isfinite(out).all()
     el = torch.tensor([elapsed], device=dev)
     if world > 1:
@@ -352,6 +360,18 @@ def main():
                                             'fp16 MFMA operands, fp32 accumulate; forward outputs follow an fp16-emulating oracle at 1e-4 '
                                             '(~1e-3 from the fp32 reference), training gradients within 1e-3 of the fp32 oracle (measured '
                                             '8.5e-4) -- reported beside the headline, never as it'}
+    if not args.no_exact and precision == 'auto':
+        # the arithmetic that holds the 1e-4 gate unconditionally (three fp16 products per term), beside the AUTO headline
+        os.environ['SUNERF_FORWARD_PRECISION'] = 'exact'
+        model._packed = None
+        xs = max(2, args.steps // 2)
+        e = timed_loop(step, xs, 2)
+        os.environ['SUNERF_FORWARD_PRECISION'] = precision
+        model._packed = None
+        extras['exact'] = {'value': rays_per_step * args.samples * world * xs / e, 'unit': 'ray-samples/s',
+                           'ms_per_step': e / xs * 1e3, 'steps': xs,
+                           'what': 'the same step with SUNERF_FORWARD_PRECISION=exact: every product from three fp16 MFMA products (fp32-class '
+                                   'results whatever the weights); the headline runs the AUTO policy (fast, guarded by a measured probe)'}
     if args.mode == 'train' and not args.no_two_pass:      # after the timed region of the headline metric
         del opt, model
         torch.cuda.empty_cache()
@@ -370,6 +390,18 @@ def main():
         # dominant kernel = the fused render pass: algorithmic GEMM FLOPs of one launch / its average duration between the
         # HIP events recorded around its launches in the timed region
         achieved = rays_per_step * args.samples * flops_fwd(D_FILTER) / (render_ms * 1e-3) / 1e12
+        # the pipelined backward (csrc/bwd_pipe.hip) is ONE kernel with the data AND weight gradients of every layer: when it
+        # runs it is the longest kernel of the step, i.e. the dominant one
+        bwd_kernel = None
+        if bwd_ms:
+            bwd_achieved = rays_per_step * args.samples * flops_bwd(D_FILTER) / (bwd_ms * 1e-3) / 1e12
+            bwd_kernel = {'kernel': 'bwd_pipe_kernel<false>' if not os.environ.get('SUNERF_PIPE_HI_ONLY') else 'bwd_pipe_kernel<true>',
+                          'kernel_ms_hip_events': bwd_ms, 'launches_timed': len(bwd_events), 'achieved': bwd_achieved,
+                          'frac': bwd_achieved / PEAK_F16_DENSE_TFLOPS, 'flops_per_sample': flops_bwd(D_FILTER),
+                          'executed_frac': bwd_achieved * (3 * 7 * D_FILTER * D_FILTER + 2 * ENC * D_FILTER) * 2 / flops_bwd(D_FILTER)
+                                           / PEAK_F16_DENSE_TFLOPS,
+                          'what': 'dgrad (W^T as fp16 head + remainder: two products) + wgrad of all layers but the out layer in one '
+                                  'persistent launch; the out layer and dZ of the last activation layer come from a 1.2 ms prologue kernel'}
         step_ms = elapsed / args.steps * 1e3
         step_achieved = rays_per_step * args.samples * flops_step / (step_ms * 1e-3) / 1e12
         # matrix-pipe work of the forward per algorithmic flop: EXACT 3 fp16 products; FAST 1 fp16 product + two 64-deep
@@ -427,6 +459,24 @@ def main():
                          'step': {'achieved': step_achieved, 'frac': step_achieved / PEAK_F16_DENSE_TFLOPS,
                                   'flops_per_sample': flops_step}},
         }
+        line['config']['backward'] = backward_used
+        if pipe_failed:
+            line['config']['backward'] = f'pipe GAVE UP (status {pipe_failed}): steps were skipped, the record is invalid'
+        if bwd_kernel:
+            if bwd_ms > render_ms:
+                # dominant kernel of the step = the pipelined backward; the render kernel's figures stay beside it
+                fwd_view = {k: line['roofline'][k] for k in ('kernel', 'kernel_ms_hip_events', 'launches_timed', 'achieved', 'frac',
+                                                             'flops_per_sample', 'executed_frac', 'arithmetic_ceiling_frac',
+                                                             'frac_of_arithmetic_ceiling', 'traffic', 'traffic_source')}
+                line['roofline'].update({k: bwd_kernel[k] for k in ('kernel', 'kernel_ms_hip_events', 'launches_timed', 'achieved', 'frac',
+                                                                    'flops_per_sample', 'executed_frac')})
+                line['roofline']['frac_of_f32_mfma_peak'] = bwd_kernel['achieved'] / PEAK_F32_MFMA_TFLOPS
+                line['roofline']['what'] = bwd_kernel['what']
+                line['roofline'].pop('arithmetic_ceiling_frac'); line['roofline'].pop('frac_of_arithmetic_ceiling')
+                line['roofline']['traffic'] = line['roofline']['traffic_source'] = None
+                line['roofline']['render_kernel'] = fwd_view
+            else:
+                line['roofline']['backward_kernel'] = bwd_kernel
         line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.res, args.samples, args.mode)

@@ -65,7 +65,9 @@ def test_dt_training_step_gradients(flat_bucket):
     if flat_bucket:
         (optimizer,), _ = lm.configure_optimizers()
         optimizer.zero_grad()
-        assert all(hasattr(p, '_sunerf_bucket') for p in lm.rendering.parameters())
+        from sunerf_hip.train import bucket_of
+        assert all(bucket_of(p) is not None for p in lm.rendering.parameters())
+        assert not any(hasattr(p, '_sunerf_bucket') for p in lm.rendering.parameters())     # nothing rides on the Parameter (pickling)
     loss = lm.training_step(batch, 0)
     assert abs(loss.item() - g['loss'].item()) < 2e-4 * abs(g['loss'].item())
     loss.backward()

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import sunerf_oracle as orc
-from conftest import load_golden
+from conftest import gate_units, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -88,9 +88,11 @@ def test_render_frame_equals_one_shot_render_and_oracle():
     sd = {k: v.cpu() for k, v in rendering.state_dict().items()}
     want = orc.render_emission(orc.params_from_state_dict(sd, 'coarse_model.'), orc.params_from_state_dict(sd, 'fine_model.'),
                                o.cpu(), d.cpu(), t.cpu(), n_coarse=32, n_fine=32, t_vals=sd['sampler.t_vals'])
+    # the north-star gate, per ray (conftest.gate_units; absorption_map = sum over 64 samples of the fp32 difference 1 - a)
     for k in ('coarse_image', 'fine_image', 'height_map', 'absorption_map'):
-        err = (frame[k].reshape(want[k].shape).cpu() - want[k]).abs().max().item() / want[k].abs().max().item()
-        assert err < 2e-4, (k, err)
+        u = gate_units(frame[k].reshape(want[k].shape), want[k], floor=64 * 6e-8 if k == 'absorption_map' else 0.0)
+        print(f'frame {k}: {u:.3f} gate units')
+        assert u <= 1.0, (k, u)
 
 
 def test_sunerf_loader_roundtrip(tmp_path):
@@ -158,10 +160,16 @@ def test_reference_written_state_file_loads_into_fused_classes():
     with torch.no_grad():
         out = loader.rendering(g['rays_o'].cuda(), g['rays_d'].cuda(), g['times'].cuda())
     assert torch.equal(out['z_vals_stratified'].cpu(), g['out__z_vals_stratified'])
-    for k in ('coarse_image', 'fine_image', 'image', 'height_map', 'absorption_map', 'regularization'):
-        ref = g['out__' + k]
-        err = (out[k].cpu() - ref).abs().max().item() / ref.abs().max().item()
-        assert err < 2e-4, (k, err)
+    n_s = g['out__regularization'].shape[-1]
+    for k in ('coarse_image', 'fine_image', 'image', 'height_map', 'absorption_map'):
+        u = gate_units(out[k], g['out__' + k], floor=n_s * 6e-8 if k == 'absorption_map' else 0.0)
+        print(f'g10 {k}: {u:.3f} gate units')
+        assert u <= 1.0, (k, u)
+    # regularization = relu(|x| - r) (1 - a): not one of the gated outputs; relative to the tensor maximum
+    ref = g['out__regularization']
+    err = (out['regularization'].cpu() - ref).abs().max().item() / ref.abs().max().item()
+    print(f'g10 regularization: {err:.2e} of the maximum (bound 2e-4)')
+    assert err < 2e-4, err
     got = loader.load_coords(g['points'].numpy())
     assert np.abs(got - g['inferences'].numpy()).max() < 1e-4 * np.abs(g['inferences'].numpy()).max()
     frame = loader.render_observer_image(lat=0.0, lon=0.2, time=datetime.datetime(2022, 3, 2))

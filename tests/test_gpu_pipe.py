@@ -1,0 +1,209 @@
+"""The layer-pipelined backward (csrc/bwd_pipe.hip, the default for d_filter = 256) against the oracle's autograd and against the
+two-kernel backward (sunerf_mlp_dgrad + sunerf_mlp_wgrad) on the same stash; robustness of its hand-off protocol (status word,
+repeated launches, ragged sizes); thread safety of the forward (evaluation/loader.py:226-229); what a trained module pickles."""
+import copy
+import io
+import threading
+
+import pytest
+import torch
+
+import sunerf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available()
+    from sunerf_hip import ops as _ops
+    return _ops
+
+
+def _case(n_side, S, n_layers=8, seed=0, hidden_scale=1.0):
+    torch.manual_seed(seed)
+    params = orc.init_params(d_filter=256, n_layers=n_layers, seed=3 + seed)
+    params = [(W * hidden_scale, b) if 0 < i < len(params) - 1 else (W, b) for i, (W, b) in enumerate(params)]
+    W, b = params[-1]
+    params[-1] = (W * 4, b)          # absorption active on about half of the samples
+    o, d = orc.synthetic_rays(n_side)
+    d = d * (0.9 + 0.2 * torch.rand(d.shape[0], 1))
+    t = torch.rand(o.shape[0], 1) * 5.
+    z = orc.stratified_z(o, d, orc.linspace_t_vals(S), torch.tensor(1.3), torch.tensor(1.0))
+    return params, o, d, t, z
+
+
+def _oracle_grads(params, o, d, t, z, g_image, g_reg_const):
+    leaves = [(W.clone().requires_grad_(True), b.clone().requires_grad_(True)) for W, b in params]
+    out = orc.render_pass(leaves, o, d, t, z)
+    dist_pts = out['points'].pow(2).sum(-1).pow(0.5)
+    reg = torch.relu(dist_pts - 1.2) * (1 - out['regularizing_quantity'])
+    ((out['image'][:, 0] * g_image).sum() + g_reg_const * reg.sum()).backward()
+    return [(W.grad, b.grad) for W, b in leaves]
+
+
+def _hip_grads(ops, mode, params, o, d, t, z, g_image, g_reg_const, reps=1, monkeypatch=None):
+    dev = torch.device('cuda')
+    Ws, bs = [W.to(dev) for W, _ in params], [b.to(dev) for _, b in params]
+    packed = ops.PackedMLP(Ws, bs, precision=ops.PRECISION_EXACT)
+    fwd = ops.emission_render_fwd(packed, o.to(dev), d.to(dev), t.to(dev), z.to(dev), reg_radius=1.2, training=True)
+    prev = ops._backward_forced
+    ops._backward_forced = mode
+    try:
+        for _ in range(reps):
+            gW = [torch.full_like(W, float('nan')) for W in Ws]
+            gb = [torch.full_like(b, float('nan')) for b in bs]
+            ops.emission_render_bwd(packed, o.to(dev), d.to(dev), z.to(dev), fwd['raw'], fwd['stash'], g_image.to(dev), None,
+                                    g_reg_const, 1.2, gW, gb)
+        torch.cuda.synchronize()
+        status = ops.pipe_status(raise_on_failure=False)
+    finally:
+        ops._backward_forced = prev
+    return [(W.cpu(), b.cpu()) for W, b in zip(gW, gb)], status
+
+
+@pytest.mark.parametrize('n_side,S,n_layers', [(6, 32, 8), (6, 40, 8), (3, 17, 8), (17, 128, 8), (9, 64, 3), (7, 96, 5), (1, 33, 8)])
+def test_pipelined_backward_matches_oracle_and_two_kernel_backward(ops, n_side, S, n_layers):
+    params, o, d, t, z = _case(n_side, S, n_layers)
+    g_image = torch.randn(o.shape[0]) * 1e-3
+    ref = _oracle_grads(params, o, d, t, z, g_image, 2e-5)
+    classic, _ = _hip_grads(ops, 'classic', params, o, d, t, z, g_image, 2e-5)
+    pipe, status = _hip_grads(ops, 'pipe', params, o, d, t, z, g_image, 2e-5)
+    assert status == 0
+    worst_ref = worst_classic = 0.0
+    for i, ((rW, rb), (cW, cb), (pW, pb)) in enumerate(zip(ref, classic, pipe)):
+        assert torch.isfinite(pW).all() and torch.isfinite(pb).all(), i
+        for name, r, c, p in (('weight', rW, cW, pW), ('bias', rb, cb, pb)):
+            e_ref = ((p - r).norm() / r.norm()).item()
+            e_cls = ((p - c).norm() / c.norm()).item()
+            worst_ref, worst_classic = max(worst_ref, e_ref), max(worst_classic, e_cls)
+            assert e_ref < 1e-3, (i, name, 'vs oracle', e_ref)
+            # same operands, same products (fp16 heads + remainders of W^T, fp16 H / cos / dZ): only the order of the fp32 sums differs
+            assert e_cls < 2e-5, (i, name, 'vs two-kernel backward', e_cls)
+    print(f'{o.shape[0]} rays x {S}, {n_layers} layers: pipelined vs oracle {worst_ref:.2e}, vs two-kernel {worst_classic:.2e}')
+
+
+def test_pipelined_backward_repeated_launches_and_accumulation(ops):
+    """The control block (counters, status) is re-initialised by every call; accumulate adds."""
+    params, o, d, t, z = _case(8, 64)
+    g_image = torch.randn(o.shape[0]) * 1e-3
+    once, s1 = _hip_grads(ops, 'pipe', params, o, d, t, z, g_image, 0.0)
+    again, s2 = _hip_grads(ops, 'pipe', params, o, d, t, z, g_image, 0.0, reps=5)
+    assert s1 == 0 and s2 == 0
+    for (aW, ab), (bW, bb) in zip(once, again):
+        assert torch.equal(aW, bW) and torch.equal(ab, bb)            # deterministic: fixed chunk -> pipeline assignment
+    dev = torch.device('cuda')
+    Ws, bs = [W.to(dev) for W, _ in params], [b.to(dev) for _, b in params]
+    packed = ops.PackedMLP(Ws, bs)
+    fwd = ops.emission_render_fwd(packed, o.to(dev), d.to(dev), t.to(dev), z.to(dev), reg_radius=1.2, training=True)
+    gW, gb = [torch.zeros_like(W) for W in Ws], [torch.zeros_like(b) for b in bs]
+    args = (packed, o.to(dev), d.to(dev), z.to(dev), fwd['raw'], fwd['stash'], g_image.to(dev), None, 0.0, 1.2, gW, gb)
+    ops.emission_render_bwd(*args)
+    first = [g.clone() for g in gW + gb]
+    ops.emission_render_bwd(*args, accumulate=True)
+    for a, b in zip(first, gW + gb):
+        assert torch.allclose(b, 2 * a, rtol=1e-5, atol=1e-12)
+    assert ops.pipe_status(raise_on_failure=False) == 0
+
+
+def test_pipelined_backward_with_amplifying_hidden_weights(ops):
+    """Hidden weights x 2: the data gradient grows from the output to the first layer; same 1e-3 per tensor."""
+    params, o, d, t, z = _case(6, 64, hidden_scale=2.0)
+    g_image = torch.randn(o.shape[0]) * 1e-3
+    ref = _oracle_grads(params, o, d, t, z, g_image, 2e-5)
+    pipe, status = _hip_grads(ops, 'pipe', params, o, d, t, z, g_image, 2e-5)
+    assert status == 0
+    worst = max(max(((pW - rW).norm() / rW.norm()).item(), ((pb - rb).norm() / rb.norm()).item()) for (rW, rb), (pW, pb) in zip(ref, pipe))
+    print(f'hidden x 2: worst tensor {worst:.2e}')
+    assert worst < 1e-3
+
+
+def test_training_batch_through_pipelined_backward(ops):
+    """A training-size batch (8192 rays x 128 samples = 32768 chunks, 2048 per pipeline): finite, status 0, equals the two-kernel
+    backward to summation order."""
+    torch.manual_seed(1)
+    params = orc.init_params(d_filter=256, n_layers=8, seed=5)
+    o, d = orc.synthetic_rays(91)
+    o, d = o[:8192].contiguous(), d[:8192].contiguous()
+    t = torch.rand(8192, 1)
+    z = orc.stratified_z(o, d, orc.linspace_t_vals(128), torch.tensor(1.3), torch.tensor(1.0))
+    g_image = torch.randn(8192) * 1e-3
+    classic, _ = _hip_grads(ops, 'classic', params, o, d, t, z, g_image, 2e-5)
+    pipe, status = _hip_grads(ops, 'pipe', params, o, d, t, z, g_image, 2e-5)
+    assert status == 0
+    for (cW, cb), (pW, pb) in zip(classic, pipe):
+        assert ((pW - cW).norm() / cW.norm()).item() < 5e-5 and ((pb - cb).norm() / cb.norm()).item() < 5e-5
+
+
+def test_render_from_four_threads_equals_serial_render(ops):
+    """evaluation/loader.py:226-229 submits the ray batches of a frame to a ThreadPoolExecutor: same frame, bit for bit, and the
+    packed-weights cache is built once."""
+    from sunerf.rendering.emission import EmissionRadiativeTransfer
+    from sunerf_hip.rays import observer_rays
+    torch.manual_seed(3)
+    rendering = EmissionRadiativeTransfer(Rs_per_ds=1.0, sampling_config={'type': 'stratified', 'n_samples': 32, 'perturb': False},
+                                          hierarchical_sampling_config={'type': 'hierarchical', 'n_samples': 32},
+                                          model_config={'d_filter': 64}).cuda()
+    o, d = observer_rays(24, device='cuda')
+    t = torch.full((o.shape[0], 1), 0.4, device='cuda')
+    chunks = [slice(i, i + 48) for i in range(0, o.shape[0], 48)]
+    results = [None] * len(chunks)
+
+    def work(tid):
+        with torch.no_grad():
+            for k in range(tid, len(chunks), 4):
+                sl = chunks[k]
+                results[k] = rendering(o[sl], d[sl], t[sl])
+
+    # threads first (cold caches: the packed images are built concurrently), then the serial frame
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        serial = [rendering(o[sl], d[sl], t[sl]) for sl in chunks]
+    for got, want in zip(results, serial):
+        assert got is not None
+        for k in want:
+            assert torch.equal(torch.nan_to_num(got[k]), torch.nan_to_num(want[k])), k
+
+
+def test_trained_module_pickles_without_the_optimiser(tmp_path):
+    """a tag on the nn.Parameter put ClipAdam (class name + both moment buffers) into every .snf written after
+    configure_optimizers().  The file of a TRAINED module names neither the optimiser nor sunerf_hip, is as small as the one
+    written before training, and deepcopy does not drag an optimiser along."""
+    from sunerf.model.sunerf import EmissionSuNeRFModule, fit_steps, save_state
+    from sunerf_hip.rays import observer_rays
+    from sunerf_hip.train import bucket_of
+
+    class _Data:
+        config = {'wcs': None}
+        Rs_per_ds, seconds_per_dt, ref_time = 1.0, 86400.0, None
+
+    torch.manual_seed(0)
+    lm = EmissionSuNeRFModule(Rs_per_ds=1.0, seconds_per_dt=86400.0, image_scaling_config={'vmax': 1.0, 'a': 0.005},
+                              sampling_config={'type': 'stratified', 'n_samples': 16},
+                              hierarchical_sampling_config={'type': 'hierarchical', 'n_samples': 16},
+                              model_config={'d_filter': 64}).cuda()
+    before = tmp_path / 'before' / 'state.snf'
+    save_state(lm, _Data, str(before))
+    o, d = observer_rays(12, device='cuda')
+    batches = [{'tracing': {'rays': torch.stack([o, d], 1), 'time': torch.rand(o.shape[0], 1, device='cuda'),
+                            'target_image': torch.rand(o.shape[0], device='cuda')}} for _ in range(3)]
+    fit_steps(lm, batches)
+    assert all(bucket_of(p) is not None for p in lm.rendering.parameters())
+    after = tmp_path / 'after' / 'state.snf'
+    save_state(lm, _Data, str(after))
+    blob = after.read_bytes()
+    assert b'ClipAdam' not in blob and b'sunerf_hip' not in blob and b'exp_avg' not in blob
+    assert len(blob) <= len(before.read_bytes()) + 4096      # (smaller, in fact: the parameters now share one flat storage)
+    loaded = torch.load(str(after), weights_only=False)
+    for (k, a), (_, b) in zip(lm.rendering.state_dict().items(), loaded['rendering'].state_dict().items()):
+        assert torch.equal(a.cpu(), b.cpu()), k
+    clone = copy.deepcopy(lm.rendering)
+    assert all(bucket_of(p) is None for p in clone.parameters())          # the copy is a free-standing module
+    buf = io.BytesIO()
+    torch.save(clone, buf)
+    assert b'ClipAdam' not in buf.getvalue()

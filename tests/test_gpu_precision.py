@@ -98,7 +98,13 @@ def test_auto_falls_back_to_exact_where_fast_leaves_the_gate(ops):
     packed._versions_since_probe = ops.PROBE_EVERY
     packed.repack([W.cuda() for W, _ in tame], [b.cuda() for _, b in tame])
     ops.emission_render_fwd(packed, o.cuda(), d.cuda(), t.cuda(), z.cuda(), reg_radius=1.2)
+    # a RE-probe is asynchronous (the step never waits for it): its decision is taken by the first render call that finds it
+    # finished -- or by wait_probe()
+    packed.wait_probe()
     assert packed.precision == ops.PRECISION_FAST
+    again = ops.emission_render_fwd(packed, o.cuda(), d.cuda(), t.cuda(), z.cuda(), reg_radius=1.2)
+    tame_fast, _ = hip_pass(ops, tame, o, d, t, z, ops.PRECISION_FAST)
+    assert torch.equal(again['image'][:, 0], tame_fast['image'])      # and it renders with the FAST image of the CURRENT weights
 
 
 def test_beyond_x8_the_reference_arithmetic_itself_is_outside_the_gate(ops):
