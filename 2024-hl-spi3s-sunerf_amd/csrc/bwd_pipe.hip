@@ -237,9 +237,15 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
 
   if (wave < 4) {
     // =============================================== data-gradient waves ===============================================
+#if defined(PIPE_PRIO) && PIPE_PRIO == 1
+    __builtin_amdgcn_s_setprio(1);
+#endif
     constexpr int NO = 2, NP_D = 6;                  // output stores / DMA pieces per iteration: dZ fragments w, 4 + w, 8 + w, 12 + w
                                                      // and the cos fragments 2 w, 2 w + 1 of this wave's own tile
-    constexpr int PF = 4;                            // B fragments requested PF k-steps ahead of their matrix instructions
+#ifndef PIPE_PF
+#define PIPE_PF 4
+#endif
+    constexpr int PF = PIPE_PF;                      // B fragments requested PF k-steps ahead of their matrix instructions
     const int U = 4 * j + wave;                      // output tile: features 32 U .. 32 U + 31 of layer l-1
     const int li = (a.n_linear - 2) - l;
     half8 wt_hi[PKS], wt_lo[HI_ONLY ? 1 : PKS];
@@ -338,6 +344,9 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   }
 
   // ================================================= weight-gradient waves =================================================
+#if defined(PIPE_PRIO) && PIPE_PRIO == 2
+  __builtin_amdgcn_s_setprio(1);
+#endif
   const int v = wave - 4;
   const bool gatew = v == 0;
   // block of this wave: row tiles 4 rq .. +3 (features of dZ_l), column tiles 2 cq, 2 cq + 1 of J_j; db_l (workgroup 0 of the

@@ -521,10 +521,11 @@ def _pipe_workspace(dev, nbytes: int) -> torch.Tensor:
     return ws
 
 
-def pipe_status(raise_on_failure: bool = True) -> int:
+def pipe_status(raise_on_failure: Optional[bool] = None) -> int:
     """Status words of the pipelined backward launches since the last call (one 4-byte read per workspace; call it where the
     step synchronises anyway).  Non-zero: a launch gave up (csrc/bwd_pipe.hip) -- its gradients were NaN, so the optimiser
-    skipped that step; the process switches to the two-kernel backward and, by default, says so loudly."""
+    skipped that step.  The process then switches to the two-kernel backward and says so: with a warning by default, with an
+    exception when ``SUNERF_BACKWARD=pipe`` was asked for explicitly (or ``raise_on_failure=True``)."""
     global _backward_forced
     worst = 0
     for key, ws in list(_pipe_checked.items()):
@@ -532,11 +533,15 @@ def pipe_status(raise_on_failure: bool = True) -> int:
         del _pipe_checked[key]
     if worst:
         _backward_forced = 'classic'
+        msg = (f'the pipelined backward gave up (status {worst}: 1 = workgroups not co-resident, 2 = a workgroup class was not '
+               'placed on one XCD, 3 = a hand-off timed out); the step was skipped (NaN gradients) and this process now uses the '
+               'two-kernel backward (SUNERF_BACKWARD=classic selects it from the start)')
+        if raise_on_failure is None:
+            raise_on_failure = os.environ.get('SUNERF_BACKWARD', '').lower() == 'pipe'
         if raise_on_failure:
-            raise _l.SunerfHipError(
-                f'the pipelined backward gave up (status {worst}: 1 = workgroups not co-resident, 2 = a workgroup class was '
-                'not placed on one XCD, 3 = a hand-off timed out); the step was skipped (NaN gradients) and this process now '
-                'uses the two-kernel backward (SUNERF_BACKWARD=classic selects it from the start)')
+            raise _l.SunerfHipError(msg)
+        import warnings
+        warnings.warn(msg, RuntimeWarning)
     return worst
 
 

@@ -313,6 +313,9 @@ def main():
         step(i)
     if getattr(model.packed(), 'auto', False):
         model.packed().wait_probe()          # the AUTO probe of the warm-up is read outside the timed region
+    if args.mode == 'train':
+        torch.cuda.synchronize()
+        ops.pipe_status(raise_on_failure=False)   # a pipelined backward that gave up in the warm-up: the timed steps use the two-kernel one
     barrier()
     recording['on'] = True
     ops.pipe_kernel_events = bwd_events
@@ -412,7 +415,7 @@ def main():
         # cap holds a pure fp16 MFMA stream at 0.72 of the nominal peak, the FAST group (4 fp16 + 2 fp8 per 64-deep product) at
         # 0.395 in useful flops, three fp16 products (EXACT) at 0.72 / 3.  No kernel computing these results can exceed it.
         arithmetic_ceiling = 0.72 if half else (0.395 if fast else 0.24)
-        traffic = traffic_source = None
+        traffic = traffic_source = bwd_traffic = None
         for tname in ('hbm_traffic.json', 'hbm_traffic_d512.json'):
             tpath = os.path.join(ROOT, 'profiles', tname)
             if not os.path.exists(tpath):
@@ -423,6 +426,7 @@ def main():
             here = {'rays': rays_per_step, 'samples': args.samples, 'd_filter': D_FILTER}
             if all(measured_on.get(k) == v for k, v in here.items()):
                 traffic = t.get(f'{args.mode}_kernel_bytes', t.get(f'{args.mode}_bytes_per_step'))
+                bwd_traffic = t.get(f'{args.mode}_bwd_kernel_bytes')
                 traffic_source = (f'profiles/{tname}: rocprofv3 PMC (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) of this '
                                   'configuration, ' + ('the render kernel alone' if f'{args.mode}_kernel_bytes' in t else
                                                        'whole step') + ' -- not measured in this run')
@@ -473,7 +477,8 @@ def main():
                 line['roofline']['frac_of_f32_mfma_peak'] = bwd_kernel['achieved'] / PEAK_F32_MFMA_TFLOPS
                 line['roofline']['what'] = bwd_kernel['what']
                 line['roofline'].pop('arithmetic_ceiling_frac'); line['roofline'].pop('frac_of_arithmetic_ceiling')
-                line['roofline']['traffic'] = line['roofline']['traffic_source'] = None
+                line['roofline']['traffic'] = bwd_traffic
+                line['roofline']['traffic_source'] = traffic_source.replace('the render kernel alone', 'the pipelined backward kernel alone') if bwd_traffic and traffic_source else None
                 line['roofline']['render_kernel'] = fwd_view
             else:
                 line['roofline']['backward_kernel'] = bwd_kernel

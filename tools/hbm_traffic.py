@@ -12,8 +12,8 @@ import json
 import os
 import sys
 
-KERNELS = ('render_fwd_kernel', 'integral_bwd', 'dgrad', 'wgrad_kernel', 'reduce_grads', 'loss_kernel', 'adam_kernel',
-           'grad_norm_kernel', 'pack_mlp')
+KERNELS = ('render_fwd_kernel', 'integral_bwd', 'dgrad', 'wgrad_kernel', 'bwd_pipe_kernel', 'bwd_prologue_kernel', 'reduce_grads',
+           'loss_kernel', 'adam_kernel', 'grad_norm_kernel', 'pack_mlp')
 
 
 def last_per_kernel(directory, counter):
@@ -46,7 +46,8 @@ def main():
                     'doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); bytes')
     data[f'{mode}_bytes_per_step'] = sum(per_kernel.values())
     data[f'{mode}_bytes_per_kernel'] = per_kernel
-    data[f'{mode}_kernel_bytes'] = per_kernel.get('render_fwd_kernel')      # the dominant kernel (bench.py: roofline.traffic)
+    data[f'{mode}_kernel_bytes'] = per_kernel.get('render_fwd_kernel')      # the fused render pass (bench.py: roofline.traffic)
+    data[f'{mode}_bwd_kernel_bytes'] = per_kernel.get('bwd_pipe_kernel')     # the pipelined backward kernel, when it ran
     data[f'{mode}_fetch_kib_raw'] = fetch
     data[f'{mode}_write_kib_raw'] = write
     data[f'{mode}_config'] = {'rays': int(rays), 'samples': int(samples), 'd_filter': int(d_filter)}
