@@ -134,6 +134,13 @@ __device__ __forceinline__ void mfma_agpr(f32x16& acc, const half8& a, const hal
 }
 __device__ __forceinline__ void drain_matrix_pipe() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
 
+// Transposed operand read straight into FOUR CONSECUTIVE, FIXED registers (the matrix instruction's operand tuple): the two
+// ds_read_b64_tr_b16 halves of tr_issue land in separate register pairs and cost 4 v_mov per operand to join -- 48 per chunk
+// in a wave whose instruction stream is the kernel's critical path.  R0..R3: VGPR numbers, OFF: immediate byte offset.
+#define TR_FIXED(R0, R1, R2, R3, OFF, var, base)                                                                        \
+  asm volatile("ds_read_b64_tr_b16 v[" #R0 ":" #R1 "], %1 offset:%2\n\tds_read_b64_tr_b16 v[" #R2 ":" #R3 "], %1 offset:%3" \
+               : "={v[" #R0 ":" #R3 "]}"(var) : "v"(base), "i"(OFF), "i"((OFF) + 64) : "memory")
+
 __device__ __forceinline__ void dz_tile(const f32x16& acc, const half8& c0, const half8& c1, half8& d0, half8& d1) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -240,8 +247,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
 #if defined(PIPE_PRIO) && PIPE_PRIO == 1
     __builtin_amdgcn_s_setprio(1);
 #endif
-    constexpr int NO = 2, NP_D = 6;                  // output stores / DMA pieces per iteration: dZ fragments w, 4 + w, 8 + w, 12 + w
-                                                     // and the cos fragments 2 w, 2 w + 1 of this wave's own tile
+    constexpr int NO = 2, NP_D = 4;                  // output stores / DMA pieces (dZ fragments w, 4 + w, 8 + w, 12 + w) per iteration
 #ifndef PIPE_PF
 #define PIPE_PF 4
 #endif
@@ -270,7 +276,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       barrier_mem();
       const unsigned ab = lds_ld(lds_abort + (it & 1) * 4);
       next_chunk(it + NBUF - 1);
-      piece_z(wave); piece_z(4 + wave); piece_z(8 + wave); piece_z(12 + wave); piece_c(2 * wave); piece_c(2 * wave + 1);
+      piece_z(wave); piece_z(4 + wave); piece_z(8 + wave); piece_z(12 + wave);
       const Rsrc sc = make_rsrc(scratch, 2048);
       const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
       buf_store(zero, sc, 0);
@@ -308,11 +314,9 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
         if constexpr (!HI_ONLY) dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt_lo[ks], bf[ks % (PF + 1)], dacc, 0, 0, 0);
         dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt_hi[ks], bf[ks % (PF + 1)], dacc, 0, 0, 0);
         if (ks == 1) piece_z(wave);
-        if (ks == 3) piece_z(4 + wave);
-        if (ks == 5) piece_z(8 + wave);
-        if (ks == 7) piece_z(12 + wave);
-        if (ks == 9) piece_c(2 * wave);
-        if (ks == 11) piece_c(2 * wave + 1);
+        if (ks == 4) piece_z(4 + wave);
+        if (ks == 7) piece_z(8 + wave);
+        if (ks == 10) piece_z(12 + wave);
         if (ks == PKS - PF) {            // the last B fragment has been requested: cos of this wave's tile
           c0f = *(const half8*)(B + (24 + 2 * wave) * 1024 + lane * 16);
           c1f = *(const half8*)(B + (25 + 2 * wave) * 1024 + lane * 16);
@@ -404,17 +408,29 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   }
 
   bool aborted = false;
-  // per iteration: two pieces (H fragments v, 4 + v -- the data waves, which have the shorter instruction stream, fetch the
-  // dZ and cos fragments); wave 4 also the flag store and the poll.
+  // per iteration: the 16 H / cos pieces of the chunk -- wave 4, which also has the flag store, the poll and the gate, takes one
+  // (H 0), waves 5, 6, 7 five each (H 1 .. 7, cos 0 .. 7 in a row) --, ALL issued in front of this wave's matrix instructions.  The two waves of a SIMD share its matrix pipe: the data wave
+  // starts its 32 matrix instructions right behind the barrier, this wave's 16 should come when those are done and the data
+  // wave is in its epilogue -- the operand reads, the gate and the DMA issue in front of them take about that long.
   // top(): counted wait, barrier, abort word, sources of the next chunk, wave 4's publication and poll.
   unsigned long long tw = 0, tb = 0;       // SUNERF_PIPE_DEBUG: shader clocks in the counted wait / the barrier
   const bool stamp = a.dbg != nullptr;
+  auto weight_pieces = [&]() __attribute__((always_inline)) {
+    if (gatew) { piece_h(0); return; }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int g = 5 * (v - 1) + q;                       // 0 .. 14 over [H 1 .. 7, cos 0 .. 7]
+      const bool is_h = g < 7;
+      const int f = is_h ? g + 1 : g - 7;
+      dma_piece_s<1>((is_h ? nh : nc) + (size_t)f * 1024, voff, nreal ? ndst + ((is_h ? 16 : 24) + f) * 1024 : lds_dummy);
+    }
+  };
   auto top = [&](int it) __attribute__((always_inline)) {
     const int nxt = it + NBUF - 1;
     unsigned long long sa = 0, sb = 0;
     if (stamp) sa = __builtin_amdgcn_s_memtime();
-    if (gatew) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * (2 + 2)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * 2) : "memory");
+    if (gatew) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * (1 + 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * 5) : "memory");
     if (stamp) sb = __builtin_amdgcn_s_memtime();
     barrier_mem();
     if (stamp) { tw += sb - sa; tb += __builtin_amdgcn_s_memtime() - sb; }
@@ -434,7 +450,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   };
   for (int it = -(NBUF - 1); it < 0; ++it) {      // prologue iterations: DMA only
     const unsigned ab = top(it);
-    piece_h(v); piece_h(4 + v);
+    weight_pieces();
     if (ab) { aborted = true; break; }
     if (gatew && it + 1 < n_my) gate(it + 1);
   }
@@ -449,12 +465,12 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     // operand bases of this wave's block: row tiles r0.. of the dZ fragments, column tiles c0.. of the H fragments; the tile
     // and k-step parts of the addresses are immediates
     const unsigned bufA = lds0 + buf * BUF_HID + laneoff + r0 * 2048, bufB = lds0 + buf * BUF_HID + laneoff + 16 * 1024 + c0 * 2048;
-    half4 alo[2][4], ahi[2][4], blo[2][2], bhi[2][2];
-    tr_issue_imm<0 * 2048>(bufA, alo[0][0], ahi[0][0]); tr_issue_imm<1 * 2048>(bufA, alo[0][1], ahi[0][1]);
-    tr_issue_imm<2 * 2048>(bufA, alo[0][2], ahi[0][2]); tr_issue_imm<3 * 2048>(bufA, alo[0][3], ahi[0][3]);
-    tr_issue_imm<0 * 2048>(bufB, blo[0][0], bhi[0][0]); tr_issue_imm<1 * 2048>(bufB, blo[0][1], bhi[0][1]);
-    piece_h(v);
-    piece_h(4 + v);
+    // operands of the two k-steps: A = dZ^T row tiles r0 .. r0 + 3, B = H column tiles c0, c0 + 1; registers v80 .. v127
+    half8 A0[4], B0[2], A1[4], B1[2];
+    TR_FIXED(80, 81, 82, 83, 0 * 2048, A0[0], bufA); TR_FIXED(84, 85, 86, 87, 1 * 2048, A0[1], bufA);
+    TR_FIXED(88, 89, 90, 91, 2 * 2048, A0[2], bufA); TR_FIXED(92, 93, 94, 95, 3 * 2048, A0[3], bufA);
+    TR_FIXED(96, 97, 98, 99, 0 * 2048, B0[0], bufB); TR_FIXED(100, 101, 102, 103, 1 * 2048, B0[1], bufB);
+    weight_pieces();
     typedef __attribute__((address_space(3))) v4u lds_v4u;
     v4u pw = {0, 0, 0, 0};
     if (gatew) pw = *(const lds_v4u*)(uintptr_t)(lds_poll + buf * 256);     // the poll that landed with this iteration's chunk
@@ -469,33 +485,24 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       if (it + 1 < n_my) gate(it + 1);
     }
     if (stamp) s2 = __builtin_amdgcn_s_memtime();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(alo[0][i]), "+v"(ahi[0][i]));
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) asm volatile("" : "+v"(blo[0][jj]), "+v"(bhi[0][jj]));
-    tr_issue_imm<0 * 2048 + 256>(bufA, alo[1][0], ahi[1][0]); tr_issue_imm<1 * 2048 + 256>(bufA, alo[1][1], ahi[1][1]);
-    tr_issue_imm<2 * 2048 + 256>(bufA, alo[1][2], ahi[1][2]); tr_issue_imm<3 * 2048 + 256>(bufA, alo[1][3], ahi[1][3]);
-    tr_issue_imm<0 * 2048 + 256>(bufB, blo[1][0], bhi[1][0]); tr_issue_imm<1 * 2048 + 256>(bufB, blo[1][1], bhi[1][1]);
+    asm volatile("" : "+v"(A0[0]), "+v"(A0[1]), "+v"(A0[2]), "+v"(A0[3]), "+v"(B0[0]), "+v"(B0[1]));
+    TR_FIXED(104, 105, 106, 107, 0 * 2048 + 256, A1[0], bufA); TR_FIXED(108, 109, 110, 111, 1 * 2048 + 256, A1[1], bufA);
+    TR_FIXED(112, 113, 114, 115, 2 * 2048 + 256, A1[2], bufA); TR_FIXED(116, 117, 118, 119, 3 * 2048 + 256, A1[3], bufA);
+    TR_FIXED(120, 121, 122, 123, 0 * 2048 + 256, B1[0], bufB); TR_FIXED(124, 125, 126, 127, 1 * 2048 + 256, B1[1], bufB);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       if (ks == 1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(alo[1][i]), "+v"(ahi[1][i]));
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) asm volatile("" : "+v"(blo[1][jj]), "+v"(bhi[1][jj]));
+        asm volatile("" : "+v"(A1[0]), "+v"(A1[1]), "+v"(A1[2]), "+v"(A1[3]), "+v"(B1[0]), "+v"(B1[1]));
       }
-      // all six operands are formed BEFORE the first matrix instruction of the k-step and a few idle cycles follow: the asm
-      // instructions get no hazard handling from hipcc, and an operand register written by a v_mov immediately in front of
-      // the matrix instruction that reads it was read stale (seen: the first tile of every k-step wrong, the others right)
-      half8 bf0 = join(blo[ks][0], bhi[ks][0]), bf1 = join(blo[ks][1], bhi[ks][1]);
-      half8 af4[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af4[i] = join(alo[ks][i], ahi[ks][i]);
-      asm volatile("s_nop 7" : "+v"(bf0), "+v"(bf1), "+v"(af4[0]), "+v"(af4[1]), "+v"(af4[2]), "+v"(af4[3]));
+      // (the asm matrix instructions get no hazard handling from hipcc: with the earlier v_mov joins an operand written
+      // immediately in front of the instruction that reads it was read stale -- the first tile of every k-step came out wrong.
+      // Now the operands are written by the LDS reads and covered by the lgkmcnt wait; two idle cycles stay as a margin.)
+      const half8 bf0 = ks ? B1[0] : B0[0], bf1 = ks ? B1[1] : B0[1];
+      asm volatile("s_nop 1" ::: "memory");
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const half8 af = af4[i];
+        const half8 af = ks ? A1[i] : A0[i];
         mfma_agpr(acc[i][0], af, bf0);
         mfma_agpr(acc[i][1], af, bf1);
         if (do_bias && (i >> 1) == cq) {
