@@ -66,7 +66,7 @@ struct PipeArgs {
   int n_linear, d_out;
   int NP, NPX;              // pipelines in all / per XCD class
   int hi_only;
-  unsigned* dbg;            // optional [workgroup][8]: loop ticks, fallback spins / ticks of the input and output link, chunks, layer, pipeline
+  unsigned* dbg;            // optional [8 regions][workgroup][8] (regions 4, 5: one iteration's timeline of pipeline 0): loop ticks, fallback spins / ticks of the input and output link, chunks, layer, pipeline
 };
 
 // control block: word 0 status, 1 arrived, 8..15 XCC masks per class; counters from word 64, each on a 128-byte line
@@ -284,6 +284,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       if (ab) { stop = true; break; }
     }
     unsigned long long ph[4] = {0, 0, 0, 0};      // SUNERF_PIPE_DEBUG: shader clocks in wait / barrier / k-steps / epilogue
+    unsigned long long tl[5] = {0, 0, 0, 0, 0};   //   and the stamps of iteration n_my / 2 themselves
     const bool stamp = a.dbg != nullptr;
     char* out_z = ring_out;                        // ring slot of this iteration's output
     int out_slot = 0;
@@ -335,11 +336,16 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       if (stamp) {
         const unsigned long long s4 = __builtin_amdgcn_s_memtime();
         ph[0] += s1 - s0; ph[1] += s2 - s1; ph[2] += s3 - s2; ph[3] += s4 - s3;
+        if (it == n_my / 2) { tl[0] = s0; tl[1] = s1; tl[2] = s2; tl[3] = s3; tl[4] = s4; }
       }
       if (ab) break;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     barrier_mem();
+    if (stamp && P == 0 && lane == 0) {      // timeline of iteration n_my / 2: [workgroup of the pipeline][wave][8] 64-bit shader clocks
+      unsigned long long* t = (unsigned long long*)(a.dbg + 256 * 8 * 4) + (((size_t)(blockIdx.x >> 3) * 8 + wave) * 8);
+      for (int k = 0; k < 5; ++k) t[k] = tl[k];
+    }
     if (stamp && wave == 1 && lane == 0) {
       unsigned* d = a.dbg + 256 * 8 + (size_t)blockIdx.x * 8;
       for (int k = 0; k < 4; ++k) d[k] = (unsigned)(ph[k] >> 4);
@@ -414,6 +420,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   // wave is in its epilogue -- the operand reads, the gate and the DMA issue in front of them take about that long.
   // top(): counted wait, barrier, abort word, sources of the next chunk, wave 4's publication and poll.
   unsigned long long tw = 0, tb = 0;       // SUNERF_PIPE_DEBUG: shader clocks in the counted wait / the barrier
+  unsigned long long t_wait = 0, t_bar = 0, tl[6] = {0, 0, 0, 0, 0, 0};
   const bool stamp = a.dbg != nullptr;
   auto weight_pieces = [&]() __attribute__((always_inline)) {
     if (gatew) { piece_h(0); return; }
@@ -433,7 +440,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * 5) : "memory");
     if (stamp) sb = __builtin_amdgcn_s_memtime();
     barrier_mem();
-    if (stamp) { tw += sb - sa; tb += __builtin_amdgcn_s_memtime() - sb; }
+    if (stamp) { t_wait = sb; t_bar = __builtin_amdgcn_s_memtime(); tw += sb - sa; tb += t_bar - sb; }
     const unsigned ab = lds_ld(lds_abort + (it & 1) * 4);     // looked at by the caller when the iteration's work is done
     next_chunk(nxt);
     if (gatew) {
@@ -519,6 +526,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     if (stamp) {
       const unsigned long long s3 = __builtin_amdgcn_s_memtime();
       ph[0] += s1 - s0; ph[1] += s2 - s1; ph[2] += s3 - s2;
+      if (it == n_my / 2) { tl[0] = s0; tl[1] = t_wait; tl[2] = t_bar; tl[3] = s1; tl[4] = s2; tl[5] = s3; }
     }
     if (ab) { aborted = true; break; }
   }
@@ -527,6 +535,10 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     unsigned* d = a.dbg + 256 * 8 * (2 + v) + (size_t)blockIdx.x * 8;
     for (int k = 0; k < 3; ++k) d[k] = (unsigned)(ph[k] >> 4);
     d[3] = (unsigned)(tw >> 4); d[4] = (unsigned)(tb >> 4);
+  }
+  if (stamp && P == 0 && lane == 0) {
+    unsigned long long* t = (unsigned long long*)(a.dbg + 256 * 8 * 4) + (((size_t)(blockIdx.x >> 3) * 8 + wave) * 8);
+    for (int k = 0; k < 6; ++k) t[k] = tl[k];
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   barrier_mem();
@@ -884,7 +896,7 @@ struct PipeLayout {
     dz_top = off; off += up((size_t)(n_chunks_total > 0 ? n_chunks_total : 1) * SLOT);
     partial = off; off += up((size_t)n_act * NP * PT * (PT + 1) * 1024 * sizeof(float));
     partial_out = off; off += up((size_t)cus * (PT + 1) * 1024 * sizeof(float));
-    dbg = off; off += up((size_t)cus * 32 * sizeof(unsigned));
+    dbg = off; off += up((size_t)cus * 64 * sizeof(unsigned));
     total = off;
   }
 };

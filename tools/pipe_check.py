@@ -72,6 +72,19 @@ def run(n_side, S, reps, d_filter=256, n_layers=8):
                     q = dbg[2 + w][sel][m].float() * 16 / n
                     line += f'\n        weight wave {4 + w} clocks/chunk: top {q[:, 0].mean():.0f} (wait {q[:, 3].mean():.0f} barrier {q[:, 4].mean():.0f}) reads+gate {q[:, 1].mean():.0f} matrix {q[:, 2].mean():.0f}'
             print(line)
+        if dbg.shape[0] >= 6:      # timeline of iteration n_my / 2 in pipeline 0: shader clocks relative to the earliest stamp of the workgroup
+            tl = dbg[4:6].reshape(-1).view(torch.int64).reshape(32, 8, 8)[:16]
+            names_d = ['top', 'landed', 'barrier', 'k-steps', 'epilogue']
+            names_w = ['top', 'landed', 'barrier', 'published', 'reads+DMA+gate', 'matrix']
+            for b in range(16):
+                t = tl[b]
+                if int(t.max()) == 0:
+                    continue
+                t0 = int(t[t > 0].min())
+                print(f'   workgroup {b} (layer {7 - b // 2 if b < 14 else 0}, half {b % 2}) at iteration n/2, clocks since its first stamp:')
+                for w in range(8):
+                    nm = names_d if w < 4 else names_w
+                    print('        wave %d: ' % w + '  '.join(f'{nm[k]} {int(t[w, k]) - t0}' for k in range(len(nm)) if int(t[w, k]) > 0))
 
 
 if __name__ == '__main__':
