@@ -187,7 +187,11 @@ int sunerf_mlp_wgrad(int d_filter, int n_linear, int d_out, const void* packedT,
  *              not co-resident, a class of workgroups was not placed on one XCD, or a hand-off timed out) -- the gradients
  *              are then NaN (the optimiser's non-finite guard skips the step) and the caller should fall back to
  *              sunerf_mlp_dgrad + sunerf_mlp_wgrad
- *   flags    : bit 0 = single fp16 W^T in the data gradient (default: fp16 head + fp16 remainder, as sunerf_mlp_dgrad)
+ *   flags    : bit 0 = single fp16 W^T in the data gradient (default: fp16 head + fp16 remainder, as sunerf_mlp_dgrad);
+ *              bit 1 = per-workgroup debug counters at the tail of the workspace; 0x10 / 0x20 / 0x40 = run only the prologue /
+ *              the pipelined kernel / the reduction (three calls give the caller event points between the launches);
+ *              bit 8 = TEST HOOK: the placement check of workgroup class 0 fails, so the launch gives up the way a really
+ *              misplaced one would (status 2, NaN gradients) -- tests/test_gpu_pipe.py exercises the fallback with it
  * Requires that no other kernel holds CUs of the device while it runs long enough to starve it (all 256 workgroups must
  * become resident; every wait is bounded, so a starved launch gives up instead of hanging). */
 size_t sunerf_bwd_pipe_workspace_bytes(int64_t n_rays, int n_samples, int d_filter, int n_linear);

@@ -135,6 +135,66 @@ def test_training_batch_through_pipelined_backward(ops):
         assert ((pW - cW).norm() / cW.norm()).item() < 5e-5 and ((pb - cb).norm() / cb.norm()).item() < 5e-5
 
 
+def test_a_launch_that_gives_up_leaves_nan_gradients_and_the_process_falls_back(ops, monkeypatch):
+    """The launch checks that every workgroup class sits on one XCD; flags bit 8 (include/sunerf_hip.h) makes that check fail the
+    way a really misplaced launch would.  Contract: status word 2, EVERY gradient NaN (so ClipAdam's non-finite guard skips the
+    step), pipe_status() warns and switches the process to the two-kernel backward -- or raises when asked to -- and the next
+    backward is finite and equal to the oracle's."""
+    from sunerf_hip import lib as _l
+    from sunerf_hip import train
+    params, o, d, t, z = _case(6, 40)
+    g_image = torch.randn(o.shape[0]) * 1e-3
+    ref = _oracle_grads(params, o, d, t, z, g_image, 2e-5)
+    monkeypatch.setattr(ops, '_backward_forced', None)
+    monkeypatch.delenv('SUNERF_BACKWARD', raising=False)
+    monkeypatch.setattr(ops, '_pipe_flags', lambda: 0x100)
+    dev = torch.device('cuda')
+    Ws, bs = [W.to(dev) for W, _ in params], [b.to(dev) for _, b in params]
+    packed = ops.PackedMLP(Ws, bs, precision=ops.PRECISION_EXACT)
+    fwd = ops.emission_render_fwd(packed, o.to(dev), d.to(dev), t.to(dev), z.to(dev), reg_radius=1.2, training=True)
+
+    def backward():
+        gW = [torch.zeros_like(W) for W in Ws]
+        gb = [torch.zeros_like(b) for b in bs]
+        ops.emission_render_bwd(packed, o.to(dev), d.to(dev), z.to(dev), fwd['raw'], fwd['stash'], g_image.to(dev), None, 2e-5, 1.2, gW, gb)
+        torch.cuda.synchronize()
+        return gW, gb
+
+    assert ops.backward_mode() == 'pipe'
+    gW, gb = backward()
+    for g in gW + gb:
+        assert torch.isnan(g).all()
+    # the optimiser skips such a step: parameters and moments untouched
+    leaves = [torch.nn.Parameter(W.clone()) for W in Ws] + [torch.nn.Parameter(b.clone()) for b in bs]
+    opt = train.ClipAdam(leaves, lr=1e-3)
+    for p, g in zip(leaves, gW + gb):
+        p.grad = g.clone()
+    before = [p.detach().clone() for p in leaves]
+    opt.step()
+    torch.cuda.synchronize()
+    for p, q in zip(leaves, before):
+        assert torch.equal(p.detach(), q)
+    with pytest.warns(RuntimeWarning, match='pipelined backward gave up'):
+        assert ops.pipe_status() == 2
+    assert ops.backward_mode() == 'classic'
+    gW, gb = backward()                               # the same call, now through sunerf_mlp_dgrad + sunerf_mlp_wgrad
+    for i, ((rW, rb), W, b) in enumerate(zip(ref, gW, gb)):
+        assert ((W.cpu() - rW).norm() / rW.norm()).item() < 1e-3, i
+        assert ((b.cpu() - rb).norm() / rb.norm()).item() < 1e-3, i
+    assert ops.pipe_status() == 0
+    # asked for explicitly, a launch that gives up is an error
+    monkeypatch.setattr(ops, '_backward_forced', None)
+    backward()
+    with pytest.raises(_l.SunerfHipError, match='status 2'):
+        ops.pipe_status(raise_on_failure=True)
+    monkeypatch.setattr(ops, '_backward_forced', None)
+    monkeypatch.setattr(ops, '_pipe_flags', lambda: 0)
+    gW, gb = backward()                               # and the kernel itself is fine again on the next launch
+    assert ops.pipe_status(raise_on_failure=False) == 0
+    for i, ((rW, rb), W, b) in enumerate(zip(ref, gW, gb)):
+        assert ((W.cpu() - rW).norm() / rW.norm()).item() < 1e-3, i
+
+
 def test_render_from_four_threads_equals_serial_render(ops):
     """evaluation/loader.py:226-229 submits the ray batches of a frame to a ThreadPoolExecutor: same frame, bit for bit, and the
     packed-weights cache is built once."""
