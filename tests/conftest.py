@@ -44,16 +44,15 @@ def precision(request, monkeypatch):
 
 
 def gate_units(got, ref, floor=0.0):
-    """The north-star bound, per ray (not relative to the tensor's maximum only):
-        |got - ref| <= 1e-4 |ref| + 1e-6 max|ref| (+ floor)
-    as max over elements of |got - ref| / bound; <= 1 passes.  For (N, W) multi-channel images the maximum is taken per
-    channel (the AIA channels differ by orders of magnitude).  ``floor``: absolute rounding noise the REFERENCE's own fp32
+    """The north-star bound, per ray and purely relative (not relative to the tensor's maximum; VERDICT r2: the
+    1e-6 max|ref| term it still had let a pixel at 1 % of the frame maximum pass at 2e-4 -- removed, every GPU test passes without):
+        |got - ref| <= 1e-4 |ref| (+ floor)
+    as max over elements of |got - ref| / bound; <= 1 passes.  ``floor``: absolute rounding noise the REFERENCE's own fp32
     evaluation carries, e.g. S * 2^-24 for absorption_map = sum over S samples of the fp32 difference (1 - a)."""
     got, ref = got.detach().cpu().double(), ref.double()
     assert got.shape == ref.shape or got.numel() == ref.numel(), (got.shape, ref.shape)
     got = got.reshape(ref.shape)
-    top = ref.abs().amax(0, keepdim=True) if ref.dim() == 2 and ref.shape[1] > 1 else ref.abs().max()
-    bound = 1e-4 * ref.abs() + 1e-6 * top + floor
+    bound = 1e-4 * ref.abs() + floor
     err = (got - ref).abs()
     if not bool((bound > 0).all()):               # an all-zero reference channel (absent wavelength): must be exactly zero too
         assert bool((err[bound == 0] == 0).all())

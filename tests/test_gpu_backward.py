@@ -77,6 +77,36 @@ def test_render_pass_backward(ops, d_filter, n_layers, S, precision):
         assert eb < 1e-3, (i, 'bias', eb)
 
 
+@pytest.mark.parametrize('d_filter,n_layers,S', [(64, 3, 32), (64, 8, 40), (128, 4, 64), (256, 8, 32), (64, 1, 32), (64, 2, 96), (512, 8, 32), (512, 2, 64), (512, 1, 32)])
+def test_render_pass_under_the_auto_policy_holds_the_forward_gate(ops, monkeypatch, d_filter, n_layers, S):
+    """The same nine networks under the DEFAULT arithmetic policy (AUTO: fast where its measured probe says the network allows
+    it, exact elsewhere): the training forward is held to the north-star gate itself -- 1e-4 per ray, no widening by the raw
+    output's scale as the forced-fast run of test_render_pass_backward needs at |r0| > 2.5 -- and the gradients to 1e-3."""
+    from conftest import gate_units
+    monkeypatch.delenv('SUNERF_FORWARD_PRECISION', raising=False)
+    params, o, d, t, z = _case(d_filter, n_layers, S)
+    g_image = torch.randn(o.shape[0]) * 1e-3
+    ref_out, ref_grads, _ = _oracle_grads(params, o, d, t, z, g_image, 2e-5)
+    dev = torch.device('cuda')
+    Ws, bs = [W.to(dev) for W, _ in params], [b.to(dev) for _, b in params]
+    packed = ops.PackedMLP(Ws, bs)
+    assert packed.auto
+    fwd = ops.emission_render_fwd(packed, o.to(dev), d.to(dev), t.to(dev), z.to(dev), reg_radius=1.2, want_epilogues=True, training=True)
+    packed.wait_probe()
+    units = gate_units(fwd['image'], ref_out['image'])
+    gW = [torch.full_like(W, float('nan')) for W in Ws]
+    gb = [torch.full_like(b, float('nan')) for b in bs]
+    ops.emission_render_bwd(packed, o.to(dev), d.to(dev), z.to(dev), fwd['raw'], fwd['stash'], g_image.to(dev), None, 2e-5, 1.2, gW, gb)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for (rW, rb), W, b in zip(ref_grads, gW, gb):
+        worst = max(worst, ((W.cpu() - rW).norm() / rW.norm()).item(), ((b.cpu() - rb).norm() / rb.norm()).item())
+    mode = {ops.PRECISION_FAST: 'fast', ops.PRECISION_EXACT: 'exact'}.get(packed.precision, packed.precision)
+    print(f'AUTO -> {mode} at {n_layers} x {d_filter}: image {units:.3f} gate units, max |raw| {ref_out["raw"].abs().max().item():.2f}, worst gradient tensor {worst:.2e}')
+    assert units <= 1.0
+    assert worst < 1e-3
+
+
 def test_backward_accumulates(ops):
     params, o, d, t, z = _case(64, 3, 32)
     dev = torch.device('cuda')

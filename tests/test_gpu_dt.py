@@ -71,6 +71,7 @@ def test_dt_training_step_gradients(flat_bucket):
     loss = lm.training_step(batch, 0)
     assert abs(loss.item() - g['loss'].item()) < 2e-4 * abs(g['loss'].item())
     loss.backward()
+    worst = {'coarse': 0.0, 'fine': 0.0}
     for name, p in lm.rendering.named_parameters():
         ref = g['grad__' + name.replace('.', '__')]
         got = p.grad.cpu()
@@ -78,7 +79,9 @@ def test_dt_training_step_gradients(flat_bucket):
             assert got.abs().max() == 0, name       # relu(negative log_absortpion): exactly no gradient
             continue
         err = ((got - ref).norm() / ref.norm()).item()
-        assert err < (3e-3 if name.startswith('fine') else 1e-3), (name, err)
+        worst['fine' if name.startswith('fine') else 'coarse'] = max(worst['fine' if name.startswith('fine') else 'coarse'], err)
+        assert err < 1e-3, (name, err)       # SURVEY's gate for every tensor (measured: coarse 2.3e-4, fine 3.6e-4)
+    print(f"DT training-step gradients: worst coarse tensor {worst['coarse']:.2e} (bound 1e-3), worst fine tensor {worst['fine']:.2e} (bound 1e-3)")
 
 
 def test_simple_star_field_and_render_match_reference():

@@ -65,7 +65,10 @@ def test_forward_matches_reference(name, d_filter, n_c, n_f, precision):
     for k in ('fine_image', 'image', 'height_map', 'absorption_map'):
         assert units[k] <= 1.0, (k, units[k])
     # (golden rays have |d| != 1: samples far from the origin amplify the error of 1 - absorption, see test_gpu_stages)
-    tol = 2e-4 if precision == 'exact' else 1e-3
+    # measured on g5 (the fixture whose regularization is not identically zero): 7.8e-5 exact, 2.2e-4 fast
+    tol = 2e-4 if precision == 'exact' else 5e-4
+    e_reg = ((out['regularization'].cpu() - g['out__regularization']).abs().max() / g['out__regularization'].abs().max().clamp_min(1e-30)).item()
+    print(f'{name} regularization ({precision}): measured {e_reg:.2e} of its maximum, bound {tol:.0e}')
     assert (out['regularization'].cpu() - g['out__regularization']).abs().max().item() \
         < tol * g['out__regularization'].abs().max().item() + 1e-7
 
@@ -117,11 +120,15 @@ def test_training_step_matches_reference_loss_and_grads(precision):
     loss = mod.training_step(batch, 0)
     assert abs(loss.item() - g['loss'].item()) < 2e-4 * abs(g['loss'].item())
     loss.backward()
+    worst = {'coarse': 0.0, 'fine': 0.0}
     for name, p in mod.rendering.named_parameters():
         ref = g['grad__' + name.replace('.', '__')]
         err = ((p.grad.cpu() - ref).norm() / ref.norm()).item()
-        # fine-model gradients sit behind the inverse-CDF resampling (tiny z differences): 3e-3; coarse: 1e-3
-        assert err < (3e-3 if name.startswith('fine') else 1e-3), (name, err)
+        worst['fine' if name.startswith('fine') else 'coarse'] = max(worst['fine' if name.startswith('fine') else 'coarse'], err)
+        # SURVEY's gate for every tensor, the fine model's too although it sits behind the inverse-CDF resampling (measured:
+        # coarse 2.2e-4, fine 4.1e-4 in both arithmetics)
+        assert err < 1e-3, (name, err)
+    print(f"training-step gradients ({precision}): worst coarse tensor {worst['coarse']:.2e} (bound 1e-3), worst fine tensor {worst['fine']:.2e} (bound 1e-3)")
 
 
 def test_fit_steps_reduces_loss():

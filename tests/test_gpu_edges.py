@@ -176,12 +176,15 @@ def test_any_width_and_no_encoding_by_exact_zero_padding(d_filter, encoding):
         assert gate_units(got[k], want[k].detach()) <= 1.0, k
     loss = ((got['coarse_image'] - target.cuda()) ** 2).mean() + ((got['fine_image'] - target.cuda()) ** 2).mean() + got['regularization'].mean()
     loss.backward()
+    worst = {}
     for m in ('coarse_model', 'fine_model'):
         for lin, (W, b) in zip(getattr(mod, m).linears(), leaves[m + '.']):
             assert lin.weight.grad.shape == W.shape
             eW = ((lin.weight.grad.cpu() - W.grad).norm() / W.grad.norm()).item()
             eb = ((lin.bias.grad.cpu() - b.grad).norm() / b.grad.norm()).item()
-            assert eW < (3e-3 if m == 'fine_model' else 1e-3) and eb < (3e-3 if m == 'fine_model' else 1e-3), (m, eW, eb)
+            worst[m] = max(worst.get(m, 0.0), eW, eb)
+            assert eW < 1e-3 and eb < 1e-3, (m, eW, eb)       # SURVEY's gate for every tensor (measured <= 3.4e-4)
+    print('padded-width module gradients, worst tensor:', {m: f'{v:.2e}' for m, v in worst.items()}, '(bound 1e-3)')
 
 
 @pytest.mark.parametrize('n_layers,S', [(8, 64), (2, 32), (3, 40)])

@@ -71,8 +71,10 @@ def test_render_pass_vs_oracle(ops, d_filter, n_layers, S, precision):
     reg = torch.relu(dist_pts - 1.2) * (1 - ref['regularizing_quantity'])
     # these rays have |d| != 1, so the samples sit up to 40 radii from the origin and relu(|p| - 1.2) multiplies the error of
     # (1 - absorption) by up to 40: 1e-4 of the maximum needs the exact arithmetic; the fp8-correction mode (raw output
-    # within 2e-5, asserted above) gets 5e-4 on this amplified quantity
-    tol = 1e-4 if precision == 'exact' else 5e-4
+    # within 2e-5, asserted above) gets 4e-4 on this amplified quantity (measured over the 15 cases: <= 1.9e-4; exact: <= 4.0e-5)
+    tol = 1e-4 if precision == 'exact' else 4e-4
+    e_reg = ((out['regularization'].cpu() - reg).abs().max() / reg.abs().max()).item()
+    print(f'regularization ({precision}): measured {e_reg:.2e} of its maximum, bound {tol:.0e}')
     assert (out['regularization'].cpu() - reg).abs().max().item() <= tol * reg.abs().max().item() + 1e-7
 
 
