@@ -25,7 +25,8 @@
 namespace {
 
 constexpr int DT_THREADS = 256;
-constexpr int DT_RAYS = DT_THREADS / 32;      // rays per workgroup
+constexpr int DT_RAYS = DT_THREADS / 32;      // rays per workgroup (and per step of its walk over the batch)
+constexpr int DT_MAX_GRID = 1024;             // backward: workgroups of the grid
 constexpr int NCH = 7;
 constexpr int NTAB = NCH * 101;
 
@@ -226,7 +227,12 @@ __global__ __launch_bounds__(DT_THREADS) void dt_integral_bwd_kernel(DtArgs a) {
   for (int i = tid; i < NTAB; i += DT_THREADS) { tab[i] = a.table_logt[i]; tab[NTAB + i] = a.table_resp[i]; }
   if (tid < 8) acc8[tid] = 0.f;
   __syncthreads();
-  const int64_t ray_raw = (int64_t)blockIdx.x * DT_RAYS + sub;
+  float local_max = 0.f;
+  // a workgroup walks over groups of DT_RAYS rays (grid <= DT_MAX_GRID) and sends its sums ONCE: 8 atomic adds and one atomic
+  // max per workgroup instead of per ray group / per wave
+  const int64_t n_groups = (a.n_rays + DT_RAYS - 1) / DT_RAYS;
+  for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+  const int64_t ray_raw = grp * DT_RAYS + sub;
   const bool ray_ok = ray_raw < a.n_rays;
   const int64_t ray = ray_ok ? ray_raw : a.n_rays - 1;
   const int S = a.S, n_chunks = (S + 31) >> 5;
@@ -247,7 +253,6 @@ __global__ __launch_bounds__(DT_THREADS) void dt_integral_bwd_kernel(DtArgs a) {
   }
   const float ox = a.rays_o[ray * 3 + 0], oy = a.rays_o[ray * 3 + 1], oz = a.rays_o[ray * 3 + 2];
   const float dx = a.rays_d[ray * 3 + 0], dy = a.rays_d[ray * 3 + 1], dz = a.rays_d[ray * 3 + 2];
-  float local_max = 0.f;
   // trapezoid weight of term_j on the grid z[0..S-2]:  wt_j = (dz_{j-1} + dz_j) / 2 with missing neighbours dropped
   auto wt = [&](int j, float zm, float z0, float zp1) {
     float w = 0.f;
@@ -327,12 +332,20 @@ __global__ __launch_bounds__(DT_THREADS) void dt_integral_bwd_kernel(DtArgs a) {
     }
   }
   if (n == 0 && g_vol != 0.f) atomicAdd(acc8 + 7, g_vol);
+  }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, d));
+  __shared__ float wave_max[DT_THREADS / 64];
+  if ((tid & 63) == 0) wave_max[tid >> 6] = local_max;
   __syncthreads();
   if (tid < NCH && acc8[tid] != 0.f) atomicAdd(a.g_log_abs + tid, acc8[tid]);
   if (tid == 7 && acc8[7] != 0.f) atomicAdd(a.g_vol_c, acc8[7]);
-  if ((tid & 63) == 0 && local_max > 0.f && local_max < INFINITY) atomicMax(a.g_absmax_bits, __float_as_uint(local_max));
+  if (tid == 0) {
+    float m = wave_max[0];
+#pragma unroll
+    for (int w = 1; w < DT_THREADS / 64; ++w) m = fmaxf(m, wave_max[w]);
+    if (m > 0.f && m < INFINITY) atomicMax(a.g_absmax_bits, __float_as_uint(m));
+  }
 }
 
 int check_common(const DtArgs& a) {
@@ -451,7 +464,9 @@ extern "C" int sunerf_dt_integral_bwd(const float* raw, const float* z_vals, con
     if (e != hipSuccess) return (int)e;
   }
   SUNERF_CLEAR_ERROR();
-  hipLaunchKernelGGL(dt_integral_bwd_kernel, dim3((unsigned)((n_rays + DT_RAYS - 1) / DT_RAYS)), dim3(DT_THREADS), lds, st, a);
+  int64_t groups = (n_rays + DT_RAYS - 1) / DT_RAYS;
+  if (groups > DT_MAX_GRID) groups = DT_MAX_GRID;
+  hipLaunchKernelGGL(dt_integral_bwd_kernel, dim3((unsigned)groups), dim3(DT_THREADS), lds, st, a);
   SUNERF_CHECK_LAUNCH();
   return 0;
 }

@@ -88,8 +88,16 @@ __global__ void reduce_grads_kernel(ReduceArgs a) {
   if (j >= rows) return;
   const size_t slot = a.slot[layer];
   const float* p = a.partial[layer] + ((size_t)tr * (T + 1) + tc) * 1024 + reg * 64 + lane;
-  float sum = 0.f;
-  for (int s = 0; s < a.split[layer]; ++s) sum += p[(size_t)s * slot];
+  // (four independent loads in flight: one dependent load per partial made this kernel latency-bound at 80 us)
+  const int ns = a.split[layer];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int s = 0;
+  for (; s + 4 <= ns; s += 4) {
+    const float v0 = p[(size_t)s * slot], v1 = p[(size_t)(s + 1) * slot], v2 = p[(size_t)(s + 2) * slot], v3 = p[(size_t)(s + 3) * slot];
+    s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+  }
+  for (; s < ns; ++s) s0 += p[(size_t)s * slot];
+  const float sum = (s0 + s1) + (s2 + s3);
   // dZ of this layer carries the boosts of every layer above it (sunerf_common.h: sunerf_bwd_boost)
   int boost = 0;
   if (a.sumsq)

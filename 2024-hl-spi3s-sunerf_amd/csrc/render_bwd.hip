@@ -25,6 +25,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int IB_THREADS = 256;                // 8 rays per workgroup
 constexpr int IB_RAYS = IB_THREADS / 32;
+constexpr int IB_MAX_GRID = 2048;              // 8 workgroups per CU
 
 __global__ __launch_bounds__(IB_THREADS) void integral_bwd_kernel(
     const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ rays_o,
@@ -34,7 +35,12 @@ __global__ __launch_bounds__(IB_THREADS) void integral_bwd_kernel(
     unsigned* __restrict__ g_absmax_bits) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [IB_RAYS][3][Sp]: emerging intensity, a, dist
   const int tid = threadIdx.x, n = tid & 31, sub = tid >> 5;
-  const int64_t ray_raw = (int64_t)blockIdx.x * IB_RAYS + sub;
+  float local_max = 0.f;
+  // a workgroup walks over groups of IB_RAYS rays (grid <= IB_MAX_GRID): ONE atomic per workgroup on the batch maximum -- with
+  // one per wave and 4096 workgroups the 16384 atomics on that single word took most of the kernel's 200 us
+  const int64_t n_groups = (n_rays + IB_RAYS - 1) / IB_RAYS;
+  for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+  const int64_t ray_raw = grp * IB_RAYS + sub;
   const bool ray_ok = ray_raw < n_rays;
   const int64_t ray = ray_ok ? ray_raw : n_rays - 1;
   const int n_chunks = (S + 31) >> 5, Sp = n_chunks * 32;
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(IB_THREADS) void integral_bwd_kernel(
     dot_over_den2 = dot_gw * inv_den * inv_den;
   }
   // ---- sweep 2 (against the ray): suffix_i = sum_{k > i} emerging_k ----
-  float local_max = 0.f, carry_suffix = 0.f;
+  float carry_suffix = 0.f;
   for (int c = n_chunks - 1; c >= 0; --c) {
     const int i = 32 * c + n;
     const bool valid = i < S;
@@ -127,10 +133,19 @@ __global__ __launch_bounds__(IB_THREADS) void integral_bwd_kernel(
       local_max = fmaxf(local_max, fmaxf(fabsf(g0), fabsf(g1)));
     }
   }
+  }
   // max |g_raw| of the batch (bit pattern of a non-negative float orders like an unsigned integer)
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, d));
-  if ((tid & 63) == 0 && local_max > 0.f && local_max < INFINITY) atomicMax(g_absmax_bits, __float_as_uint(local_max));
+  __shared__ float wave_max[IB_THREADS / 64];
+  if ((tid & 63) == 0) wave_max[tid >> 6] = local_max;
+  __syncthreads();
+  if (tid == 0) {
+    float m = wave_max[0];
+#pragma unroll
+    for (int w = 1; w < IB_THREADS / 64; ++w) m = fmaxf(m, wave_max[w]);
+    if (m > 0.f && m < INFINITY) atomicMax(g_absmax_bits, __float_as_uint(m));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -661,7 +676,8 @@ extern "C" int sunerf_emission_integral_bwd(const float* raw, const float* z_val
     e = hipFuncSetAttribute((const void*)integral_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  const int64_t blocks = (n_rays + IB_RAYS - 1) / IB_RAYS;
+  int64_t blocks = (n_rays + IB_RAYS - 1) / IB_RAYS;
+  if (blocks > IB_MAX_GRID) blocks = IB_MAX_GRID;
   SUNERF_CLEAR_ERROR();
   hipLaunchKernelGGL(integral_bwd_kernel, dim3((unsigned)blocks), dim3(IB_THREADS), lds, (hipStream_t)stream, raw, z_vals,
                      rays_o, rays_d, g_image, g_reg, g_weights, g_absorption, g_reg_const, reg_radius, n_rays, n_samples, g_raw,
