@@ -1,7 +1,11 @@
 """Randomised parity sweep of the render pass (forward AND parameter gradients) against the CPU oracle: random ray counts,
 sample counts (ragged: not multiples of 32), widths, depths, weight scales and both forward arithmetics.  Development aid, run
 on the GPU box:  python tools/fuzz_parity.py [n_cases] [seed].  Prints one line per case; exits 1 if any case is outside the
-gates (raw 5e-5 abs FAST / 1e-5 EXACT at O(1) outputs, image / weights 1e-4 of the tensor scale, gradients 1.5e-3 rel L2)."""
+gates (raw 5e-5 abs FAST / 1e-5 EXACT at O(1) outputs, image / weights 1e-4 of the tensor scale, gradients 1.5e-3 rel L2).
+Known: with seed 1, cases 23, 37 and 57 (34 ... 1100 samples in all) miss the gradient gate on BIAS tensors only (FUZZ_VERBOSE=<case>
+prints every tensor): db = sum over samples of dZ cancels to a few per cent of its terms there, so the fp16 rounding of dZ -- 5e-4
+of each term, what the weight tensors of the same cases show -- is 2e-3 ... 3e-2 of the sum.  Unchanged since round 2; batches of
+training size average it out (tests/test_gpu_edges.py::test_training_batch_properties)."""
 import os
 import random
 import sys
