@@ -61,6 +61,72 @@ def test_argument_errors_without_gpu(lib):
     assert lib.sunerf_render_workspace_bytes(256) == 0 and lib.sunerf_render_workspace_bytes(512) == 1024 * 4 * 32 * 2048
 
 
+def test_pipelined_backward_entry_points_without_gpu(lib):
+    """include/sunerf_hip.h: the pipelined backward is for a 256-CU device -- without one the workspace query says 0 (= use
+    sunerf_mlp_dgrad + sunerf_mlp_wgrad) and bad arguments are refused before anything touches a device."""
+    import ctypes
+    assert lib.sunerf_bwd_pipe_workspace_bytes(100, 128, 256, 9) == 0
+    assert lib.sunerf_bwd_pipe_workspace_bytes(100, 128, 512, 9) == 0
+    GW, GB = (ctypes.c_void_p * 9)(), (ctypes.c_void_p * 9)()
+    assert lib.sunerf_mlp_backward_pipe(256, 9, 2, None, None, None, None, 4, 128, None, 0, None, None, 0, 0, None) == -1
+    assert lib.sunerf_mlp_backward_pipe(256, 9, 2, None, None, None, None, 4, 128, None, 0, GW, GB, 0, 0, None) == -1
+    assert lib.sunerf_mlp_backward_pipe(256, 9, 2, None, None, None, None, 0, 128, None, 0, GW, GB, 0, 0, None) == -1
+
+
+def test_environment_switches(monkeypatch):
+    """One parser for every on / off switch ('0', 'false', 'no', 'off', '' are OFF: VERDICT r2 found bool('0') in two places);
+    SUNERF_BACKWARD accepts exactly its two values."""
+    from sunerf_hip import ops, train
+    for v, want in (('', False), ('0', False), ('false', False), ('No', False), (' off ', False), ('1', True), ('yes', True), ('on', True)):
+        monkeypatch.setenv('SUNERF_OVERLAP', v)
+        assert train.env_flag('SUNERF_OVERLAP') is want, v
+    monkeypatch.delenv('SUNERF_OVERLAP')
+    assert train.env_flag('SUNERF_OVERLAP') is False
+    monkeypatch.setattr(ops, '_backward_forced', None)
+    monkeypatch.delenv('SUNERF_BACKWARD', raising=False)
+    assert ops.backward_mode() == 'pipe'
+    monkeypatch.setenv('SUNERF_BACKWARD', 'Classic')
+    assert ops.backward_mode() == 'classic'
+    monkeypatch.setenv('SUNERF_BACKWARD', 'fused')
+    with pytest.raises(ValueError):
+        ops.backward_mode()
+    monkeypatch.setenv('SUNERF_PIPE_DEBUG', '0')
+    monkeypatch.setenv('SUNERF_PIPE_HI_ONLY', 'off')
+    assert ops._pipe_flags() == 0
+    monkeypatch.setenv('SUNERF_PIPE_DEBUG', '1')
+    assert ops._pipe_flags() == 2
+
+
+def test_bucket_registry_is_keyed_by_identity_and_holds_no_strong_references():
+    """The optimiser finds its flat bucket through an identity-keyed weak registry, not through an attribute on the Parameter
+    (the attribute pickled the optimiser into every checkpoint)."""
+    import copy
+    import gc
+    import pickle
+    import weakref
+    from sunerf_hip import train
+
+    class Owner:
+        pass
+
+    owner = Owner()
+    p = torch.nn.Parameter(torch.zeros(3))
+    q = torch.nn.Parameter(torch.zeros(3))          # equal VALUES must not collide (identity, not __eq__)
+    assert train.bucket_of(p) is None
+    train._BUCKETS[p] = (weakref.ref(owner), 5, 3)
+    got = train.bucket_of(p)
+    assert got is not None and got[0] is owner and tuple(got[1:]) == (5, 3)
+    assert train.bucket_of(q) is None and train.bucket_of(copy.deepcopy(p)) is None
+    assert b'Owner' not in pickle.dumps(p)           # nothing rides on the Parameter
+    del owner, got
+    gc.collect()
+    assert train.bucket_of(p) is None                # a dead optimiser's tag is no tag
+    n = len(train._BUCKETS)
+    del p
+    gc.collect()
+    assert len(train._BUCKETS) == n - 1              # and a dead Parameter leaves no entry behind
+
+
 def test_cpu_tensors_are_refused():
     from sunerf_hip import ops, SunerfHipError
     with pytest.raises(SunerfHipError):
