@@ -34,6 +34,8 @@
 // writes NaN gradients, which the optimiser's non-finite guard skips, and the host falls back to the two-kernel backward).
 // Every spin is bounded by s_memrealtime and watches the status word, so the grid always drains.
 #include "grad_common.h"
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -882,9 +884,12 @@ __global__ __launch_bounds__(WG_PRE, 1) void bwd_prologue_kernel(PipeArgs a) {
   }
 }
 
+// Workspace: [sticky status block 256 B][debug counters][control block][rings + dummy-store scratch][dz_top][partial sums].
+// The first two have FIXED offsets (SUNERF_PIPE_WS_STICKY / SUNERF_PIPE_WS_DEBUG in the header) whatever the batch size, so a
+// caller that keeps one workspace for launches of different sizes always finds them.
 struct PipeLayout {
   int n_act, n_links, NPX, NP, grid;
-  size_t ctrl, rings, dz_top, partial, partial_out, dbg, total;
+  size_t sticky, dbg, ctrl, rings, dz_top, partial, partial_out, total;
   PipeLayout(int64_t n_chunks_total, int n_linear, int cus) {
     n_act = n_linear - 1;
     n_links = n_act - 1;
@@ -893,15 +898,23 @@ struct PipeLayout {
     NP = 8 * NPX;
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     size_t off = 0;
+    sticky = off; off += SUNERF_PIPE_WS_DEBUG;
+    dbg = off; off += up((size_t)cus * 64 * sizeof(unsigned));
     ctrl = off; off += up(ctrl_bytes(NP, n_links));
     rings = off; off += up((size_t)NP * n_links * RING * SLOT + (size_t)cus * 4 * 2048);
     dz_top = off; off += up((size_t)(n_chunks_total > 0 ? n_chunks_total : 1) * SLOT);
     partial = off; off += up((size_t)n_act * NP * PT * (PT + 1) * 1024 * sizeof(float));
     partial_out = off; off += up((size_t)cus * (PT + 1) * 1024 * sizeof(float));
-    dbg = off; off += up((size_t)cus * 64 * sizeof(unsigned));
     total = off;
   }
 };
+static_assert(SUNERF_PIPE_WS_STICKY == 0 && SUNERF_PIPE_WS_DEBUG == 256, "fixed offsets of the workspace header");
+
+// flags bit 7: the pipelined kernel of every call is bracketed by library-owned HIP events on the launch stream; read (and
+// cleared) by sunerf_bwd_pipe_kernel_time.  The product's call sequence stays one C-ABI call per backward.
+struct TimedLaunch { hipEvent_t e0, e1; };
+std::mutex g_timed_mutex;
+std::vector<TimedLaunch> g_timed;
 
 bool pipe_supported(int d_filter, int n_linear, int d_out, int cus) {
   return d_filter == PD && n_linear >= 3 && n_linear <= SUNERF_MAX_LAYERS && d_out >= 1 && d_out <= 2 && cus == 256 &&
@@ -946,27 +959,31 @@ extern "C" int sunerf_mlp_backward_pipe(int d_filter, int n_linear, int d_out, c
   a.NP = L.NP; a.NPX = L.NPX; a.hi_only = flags & 1; a.inject = (flags >> 8) & 1;
   a.dbg = (flags & 2) ? (unsigned*)(ws + L.dbg) : nullptr;
   hipError_t e;
-  // flags 0x10 / 0x20 / 0x40: run ONLY the prologue / the pipelined kernel / the reduction (a caller that wants events between
-  // the three launches -- bench.py's roofline line -- makes three calls); none of them set: all three
-  const int only = flags & 0x70;
-  const bool do_pre = !only || (only & 0x10), do_pipe = !only || (only & 0x20), do_red = !only || (only & 0x40);
-  if (do_pre && (e = hipMemsetAsync(ws + L.ctrl, 0, L.rings - L.ctrl, st)) != hipSuccess) return (int)e;
+  // the control block (launch status, arrival counter, XCC masks, hand-off counters) starts from zero in every launch; the
+  // sticky block in front of it is only ever OR-ed into (reduce_grads_kernel) and belongs to the caller
+  if ((e = hipMemsetAsync(ws + L.ctrl, 0, L.rings - L.ctrl, st)) != hipSuccess) return (int)e;
   const size_t lds_pre = (size_t)NBUF * BUF_PRE + 1024;
   const size_t lds_pipe = (size_t)NBUF * BUF_HID + 1024 + NBUF * 256 + 64;
   if ((e = hipFuncSetAttribute((const void*)bwd_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pre)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)bwd_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)bwd_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe)) != hipSuccess) return (int)e;
+  TimedLaunch tl = {nullptr, nullptr};
+  if (flags & 0x80) {
+    if ((e = hipEventCreate(&tl.e0)) != hipSuccess) return (int)e;
+    if ((e = hipEventCreate(&tl.e1)) != hipSuccess) { (void)hipEventDestroy(tl.e0); return (int)e; }
+  }
   SUNERF_CLEAR_ERROR();
-  if (do_pre) {
-    hipLaunchKernelGGL(bwd_prologue_kernel, dim3((unsigned)cus), dim3(WG_PRE), lds_pre, st, a);
-    SUNERF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bwd_prologue_kernel, dim3((unsigned)cus), dim3(WG_PRE), lds_pre, st, a);
+  SUNERF_CHECK_LAUNCH();
+  if (tl.e0) (void)hipEventRecord(tl.e0, st);
+  if (a.hi_only) hipLaunchKernelGGL(bwd_pipe_kernel<true>, dim3((unsigned)cus), dim3(WG), lds_pipe, st, a);
+  else hipLaunchKernelGGL(bwd_pipe_kernel<false>, dim3((unsigned)cus), dim3(WG), lds_pipe, st, a);
+  if (tl.e0) {
+    (void)hipEventRecord(tl.e1, st);
+    std::lock_guard<std::mutex> lock(g_timed_mutex);
+    g_timed.push_back(tl);
   }
-  if (do_pipe) {
-    if (a.hi_only) hipLaunchKernelGGL(bwd_pipe_kernel<true>, dim3((unsigned)cus), dim3(WG), lds_pipe, st, a);
-    else hipLaunchKernelGGL(bwd_pipe_kernel<false>, dim3((unsigned)cus), dim3(WG), lds_pipe, st, a);
-    SUNERF_CHECK_LAUNCH();
-  }
-  if (!do_red) return 0;
+  SUNERF_CHECK_LAUNCH();
   ReduceArgs r;
   const size_t slot = (size_t)PT * (PT + 1) * 1024;
   for (int i = 0; i < n_linear; ++i) {
@@ -986,7 +1003,29 @@ extern "C" int sunerf_mlp_backward_pipe(int d_filter, int n_linear, int d_out, c
   r.g_absmax_bits = (const unsigned*)g_absmax; r.n_linear = n_linear; r.D = d_filter; r.d_out = d_out; r.accumulate = accumulate;
   r.sumsq = (const float*)((const char*)packedT + sunerf_packed_mlp_t_bytes(d_filter, n_linear) - SUNERF_MAX_LAYERS * sizeof(float));
   r.status = a.ctrl;
+  r.sticky = (unsigned*)(ws + L.sticky);
   hipLaunchKernelGGL(reduce_grads_kernel, dim3(PT * (PT + 1) * 1024 / 256, n_linear), dim3(256), 0, st, r);
   SUNERF_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int sunerf_bwd_pipe_kernel_time(double* total_ms, int* launches) {
+  std::vector<TimedLaunch> mine;
+  {
+    std::lock_guard<std::mutex> lock(g_timed_mutex);
+    mine.swap(g_timed);
+  }
+  double sum = 0.0;
+  int n = 0, rc = 0;
+  for (const TimedLaunch& t : mine) {
+    float ms = 0.f;
+    hipError_t e = hipEventSynchronize(t.e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, t.e0, t.e1);
+    if (e == hipSuccess) { sum += ms; ++n; } else rc = (int)e;
+    (void)hipEventDestroy(t.e0);
+    (void)hipEventDestroy(t.e1);
+  }
+  if (total_ms) *total_ms = sum;
+  if (launches) *launches = n;
+  return rc;
 }

@@ -56,12 +56,19 @@ struct ReduceArgs {
   const float* sumsq;      // per-layer sums of squares at the tail of the transposed image (the boosts folded into W^T), or null
   const unsigned* status;  // optional: a non-zero word (the pipelined backward gave up) turns every gradient into NaN, so that
                            // the optimiser's non-finite guard skips the step instead of applying garbage
+  unsigned* sticky;        // optional: receives max(sticky, status).  The status word is cleared in front of every launch and one
+                           // workspace serves all launches of a stream (fine model, then coarse: a give-up of the first would be
+                           // erased by the second before the host looks); this word is only ever raised, the host reads and clears it
 };
 
 // one thread per element of every dW / db: sums the split partials, unscales, writes nn.Linear layouts
 __global__ void reduce_grads_kernel(ReduceArgs a) {
   const int layer = blockIdx.y;
   const int D = a.D;
+  if (a.status && a.sticky && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    const unsigned st = *a.status;
+    if (st) atomicMax(a.sticky, st);
+  }
   const int rows = (layer == a.n_linear - 1) ? a.d_out : D;
   const int cols = (layer == 0) ? SUNERF_ENC_DIM : D;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;

@@ -271,6 +271,12 @@ struct Mlp {
   static __device__ __forceinline__ void start(Ring<D>& ring, Pipe& p) {
     ring.template issue_page<0>();
     ring.template issue_page<0>();
+#if SUNERF_ABL_NO_DMA
+    ring.template issue_page<0>();
+    ring.template issue_page<0>();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ring.priming = false;
+#endif
     ring.acquire();
     // the pass starts at page phase 0, i.e. in the middle of a trickle cycle that began at the acquire phase: deal out
     // the pieces of page 2 that the k-steps between the acquire phase and the page end would have issued

@@ -15,6 +15,12 @@
 #ifndef SUNERF_DBG_KIND
 #define SUNERF_DBG_KIND 1
 #endif
+// SUNERF_ABL_NO_DMA (round 4, tools/experiments/r4_fwd_dma.sh): timing-only ablation -- the ring is filled once with real
+// pages and never refilled: what the weight stream (its LDS-DMA instructions, its L2 -> LDS traffic) costs the forward.
+// Outputs are wrong, operands stay finite.
+#ifndef SUNERF_ABL_NO_DMA
+#define SUNERF_ABL_NO_DMA 0
+#endif
 namespace sunerf_ring {
 
 constexpr int WAVES = 4;
@@ -47,6 +53,9 @@ struct Ring {
   unsigned dst;          // LDS byte address of this wave's quarter of the ring slot to fill next
   unsigned dst_first;    // ... of slot 0
   unsigned voff;         // lane * 16
+#if SUNERF_ABL_NO_DMA
+  bool priming = true;
+#endif
 
   __device__ __forceinline__ void init(const char* packed, size_t stream_bytes, unsigned lds_base, int wave, int lane) {
     const unsigned quarter = __builtin_amdgcn_readfirstlane(wave) * (PAGE / WAVES);
@@ -64,6 +73,9 @@ struct Ring {
   template <int J>
   __device__ __forceinline__ void issue_piece() {
     static_assert(J >= 0 && J < PIECES, "piece index");
+#if SUNERF_ABL_NO_DMA
+    if (priming)
+#endif
     {
       const char* sg = src + (J / 4) * 4096;
       const unsigned dg = dst + (J / 4) * 4096;

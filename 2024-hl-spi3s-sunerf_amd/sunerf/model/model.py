@@ -71,6 +71,12 @@ class NeRF(nn.Module):
     _packed = None
     _packed_key = None
 
+    def _replicate_for_data_parallel(self):
+        # a model wrapped by itself (nn.DataParallel(rendering.fine_model), evaluation/loader.py:33-36 of the reference): see
+        # sunerf.rendering.base_tracing.refuse_data_parallel
+        from sunerf.rendering.base_tracing import refuse_data_parallel
+        refuse_data_parallel(type(self).__name__)
+
     def __init__(self, d_input: int = 4, d_output: int = 2, n_layers: int = 8, d_filter: int = 512,
                  skip: Tuple[int] = (), encoding='positional'):
         super().__init__()

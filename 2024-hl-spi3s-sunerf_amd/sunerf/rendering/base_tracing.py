@@ -56,6 +56,21 @@ def field_on_query_points(model, query_points, rays_o, rays_d, z_vals):
     return raw.reshape(*query_points.shape[:-1], raw.shape[-1]), rest
 
 
+def refuse_data_parallel(what: str):
+    """``nn.DataParallel`` (the reference's ``strategy='dp'``, run_emission.py:64-69 / run_density_temperature.py:80-85, chosen
+    there whenever more than one GPU is visible) replicates the module per device inside ONE process on every forward.  The
+    fused renderer keeps per-module state that such replicas would share or lose -- the packed-weights image in the memory of
+    the device it was packed on, the flat gradient bucket the backward kernels write into -- so a replica is refused here,
+    loudly, at the moment ``torch.nn.parallel.replicate`` asks for it, instead of computing on another device's memory."""
+    from sunerf_hip.lib import SunerfHipError
+    raise SunerfHipError(
+        f"{what}: nn.DataParallel / strategy='dp' is not supported by the fused MI355X renderer.  Multi-GPU training is one "
+        "process per GPU with an RCCL all-reduce of the gradient bucket: launch the UNCHANGED run script through the wrapper, "
+        "`python -m torch.distributed.run --nproc-per-node <N> -m sunerf.run_mi355x <run_emission.py|run_density_temperature.py> "
+        "--config ...` (every rank then sees one GPU and the script picks its single-device branch), or set "
+        "`devices=1` yourself under torch.distributed.run; see INTEGRATION.md section 3.")
+
+
 class SuNeRFRendering(nn.Module):
     """base_tracing.py:8-132: owns the two samplers and the coarse / fine field models.
 
@@ -73,6 +88,9 @@ class SuNeRFRendering(nn.Module):
         self.sampler_hierarchical = _from_config(_RESAMPLERS, hierarchical_sampling_config, 'hierarchical')
         model_config = model_config or {}
         self.coarse_model, self.fine_model = model(**model_config), model(**model_config)
+
+    def _replicate_for_data_parallel(self):
+        refuse_data_parallel(type(self).__name__)
 
     def regularization(self, distance, regularizing_quantity):
         # base_tracing.py:43-44 with D2 resolved: (N, S)

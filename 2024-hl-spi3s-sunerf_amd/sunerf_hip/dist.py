@@ -64,3 +64,40 @@ class GradBucket:
         coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
         self.flat.mul_(coef)
         return total
+
+
+def device_identity(dev) -> tuple:
+    """(host, what identifies the physical GPU behind ``dev`` in this process) -- compared across ranks by
+    :func:`ranks_share_a_device`."""
+    import socket
+    props = torch.cuda.get_device_properties(dev)
+    ident = getattr(props, 'uuid', None)
+    if ident is None or not str(ident).strip('0-'):      # (some ROCm builds report an all-zero uuid)
+        ident = tuple(getattr(props, k, None) for k in ('pci_domain_id', 'pci_bus_id', 'pci_device_id'))
+    return socket.gethostname(), str(ident)
+
+
+def any_shared(identities) -> bool:
+    """True when two ranks of ``identities`` (one :func:`device_identity` per rank) name the same GPU."""
+    identities = list(identities)
+    return len(set(identities)) < len(identities)
+
+
+_shared_cache = {}
+
+
+def ranks_share_a_device(dev, group=None) -> bool:
+    """Collective (every rank of ``group`` must call it at the same point): do two ranks drive the same physical GPU?  The
+    layer-pipelined backward needs all 256 of its workgroups resident at once, each filling a whole CU; ranks that share a card
+    (CPU-style rehearsals of the multi-rank path on one GPU) would starve each other's launches into their time-outs, so they
+    take the two-kernel backward.  One all_gather_object per (device, group), cached."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+        return False
+    key = (str(dev), id(group))
+    if key not in _shared_cache:
+        mine = device_identity(dev)
+        everyone = [None] * dist.get_world_size(group)
+        dist.all_gather_object(everyone, mine, group=group)
+        _shared_cache[key] = any_shared(everyone)
+    return _shared_cache[key]
+

@@ -53,6 +53,7 @@ _SIGNATURES = {
                                                  ctypes.c_int64, ctypes.c_int, c_void, ctypes.c_size_t,
                                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
                                                  ctypes.c_int, c_void]),
+    'sunerf_bwd_pipe_kernel_time': (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     'sunerf_dt_integral_fwd': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, c_f32p, c_f32p, c_f32p,
                                                c_f32p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                                ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
@@ -103,7 +104,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.sunerf_abi_version() != 7:
+        if lib.sunerf_abi_version() != 8:
             raise SunerfHipError('libsunerf_hip.so ABI version mismatch')
         _lib = lib
     return _lib

@@ -39,6 +39,19 @@ PROBE_LIMIT = 0.5
 # MAX-all-reduced first, so every rank takes the same arithmetic at the same parameter version (equal step times, no rank-dependent
 # forward).
 PROBE_ASYNC = True
+# Under a process group the decision of an asynchronous probe is taken at a DETERMINISTIC point -- the first render call at
+# least PROBE_APPLY_AFTER parameter versions after the probe (its event has long completed by then; the call synchronises on it
+# to be sure) -- not whenever event.query() first returns true, which differs from rank to rank.  Every rank takes part in the
+# MAX all-reduce of the units whatever its own batch looks like (an empty batch contributes 0).
+PROBE_APPLY_AFTER = 2
+probe_group = None            # process group of the probe's all-reduce (None = the default group); ClipAdam(group=...) sets it
+
+
+def _probe_world() -> int:
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(probe_group)
+    return 1
 
 
 def default_precision(d_filter: int) -> int:
@@ -178,40 +191,46 @@ class PackedMLP:
         n = min(PROBE_RAYS, total)
         self.probe_due = False
         self._versions_since_probe = 0
-        if n == 0:
+        world = _probe_world()
+        if n == 0 and world <= 1:
             return 0.0
-        # PROBE_RAYS rays spread evenly over the call (the first rays of a frame are an off-disk corner of the image)
-        sel = slice(0, (total // n) * n, total // n)
-        rays_o, rays_d, z_vals = rays_o[sel].contiguous(), rays_d[sel].contiguous(), z_vals[sel].contiguous()
-        times = times.reshape(-1)[sel].contiguous()
-        if getattr(self, '_alt_buffer', None) is None:
-            self._alt_buffer = torch.empty_like(self.buffer)
-        other = PRECISION_EXACT if self.precision == PRECISION_FAST else PRECISION_FAST
-        self._pack_into(self._alt_buffer, other)
-        self._alt_version = self._version
-        views = {self.precision: self.buffer, other: self._alt_buffer}
-        outs = {}
-        for mode, buf in views.items():
-            shadow = object.__new__(PackedMLP)
-            shadow.__dict__.update(self.__dict__)
-            shadow.buffer, shadow.precision, shadow.auto = buf, mode, False
-            outs[mode] = emission_render_fwd(shadow, rays_o, rays_d, times, z_vals, reg_radius, want_epilogues=True)
         units = torch.zeros(1, dtype=torch.float32, device=self.device)
-        for k in ('image', 'height_map', 'absorption_map'):
-            f, e = outs[PRECISION_FAST][k].reshape(-1), outs[PRECISION_EXACT][k].reshape(-1)
-            # absorption_map = sum(1 - a): the reference forms 1 - a in fp32, i.e. with 2^-24 absolute noise per sample
-            floor = z_vals.shape[1] * 6e-8 if k == 'absorption_map' else 0.0
-            units = torch.maximum(units, ((f - e).abs() / (1e-4 * e.abs() + 1e-6 * e.abs().max() + floor)).max())
-        units = torch.nan_to_num(units, nan=float('inf'))      # NaN: non-finite outputs in either mode -> EXACT; the finite check reports them
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(units, op=dist.ReduceOp.MAX)       # every rank probes at the same parameter version: one decision
+        if n > 0:
+            # PROBE_RAYS rays spread evenly over the call (the first rays of a frame are an off-disk corner of the image)
+            sel = slice(0, (total // n) * n, total // n)
+            rays_o, rays_d, z_vals = rays_o[sel].contiguous(), rays_d[sel].contiguous(), z_vals[sel].contiguous()
+            times = times.reshape(-1)[sel].contiguous()
+            if getattr(self, '_alt_buffer', None) is None:
+                self._alt_buffer = torch.empty_like(self.buffer)
+            other = PRECISION_EXACT if self.precision == PRECISION_FAST else PRECISION_FAST
+            self._pack_into(self._alt_buffer, other)
+            self._alt_version = self._version
+            views = {self.precision: self.buffer, other: self._alt_buffer}
+            outs = {}
+            for mode, buf in views.items():
+                shadow = object.__new__(PackedMLP)
+                shadow.__dict__.update(self.__dict__)
+                shadow.buffer, shadow.precision, shadow.auto, shadow._pending_probe = buf, mode, False, None
+                outs[mode] = emission_render_fwd(shadow, rays_o, rays_d, times, z_vals, reg_radius, want_epilogues=True)
+            for k in ('image', 'height_map', 'absorption_map'):
+                f, e = outs[PRECISION_FAST][k].reshape(-1), outs[PRECISION_EXACT][k].reshape(-1)
+                # absorption_map = sum(1 - a): the reference forms 1 - a in fp32, i.e. with 2^-24 absolute noise per sample.
+                # The 1e-6 max|exact| term is NOT part of the parity gate (tests/conftest.py:gate_units is purely relative): it
+                # keeps rays whose exact value is (next to) zero -- off-disk rays of a frame -- from deciding the arithmetic of
+                # the whole image by 0 / 0; it can only make the probe more lenient on rays 1e-2 below the brightest one.
+                floor = z_vals.shape[1] * 6e-8 if k == 'absorption_map' else 0.0
+                units = torch.maximum(units, ((f - e).abs() / (1e-4 * e.abs() + 1e-6 * e.abs().max() + floor)).max())
+            units = torch.nan_to_num(units, nan=float('inf'))      # NaN: non-finite outputs in either mode -> EXACT; the finite check reports them
+        if world > 1:
+            import torch.distributed as dist
+            # every rank probes at the same parameter version and takes part whatever its own batch holds: one decision
+            dist.all_reduce(units, op=dist.ReduceOp.MAX, group=probe_group)
         host = torch.empty(1, dtype=torch.float32, pin_memory=True)
         host.copy_(units, non_blocking=True)
         event = torch.cuda.Event()
         event.record(torch.cuda.current_stream(self.device))
         first = self.last_probe is None
-        self._pending_probe = (host, event, float(sensitivity))
+        self._pending_probe = (host, event, float(sensitivity), self._version, world > 1)
         self._apply_probe(block=first or not PROBE_ASYNC)
         return self.last_probe
 
@@ -220,8 +239,13 @@ class PackedMLP:
         pending = self._pending_probe
         if pending is None:
             return
-        host, event, sensitivity = pending
+        host, event, sensitivity, version, collective = pending
         if block:
+            event.synchronize()
+        elif collective:
+            # ranks must switch at the same parameter version: a fixed distance behind the probe, not "when the event is seen"
+            if self._version < version + PROBE_APPLY_AFTER:
+                return
             event.synchronize()
         elif not event.query():
             return
@@ -230,14 +254,15 @@ class PackedMLP:
         self.last_probe = units
         want = PRECISION_FAST if units <= PROBE_LIMIT else PRECISION_EXACT
         if want != self.precision:
-            # (the image of the other mode was packed by the probe from the weights of ITS parameter version; a newer
-            # version re-packs the active buffer anyway, in the mode chosen here)
-            if getattr(self, '_alt_version', None) == self._version:
-                self.buffer, self._alt_buffer = self._alt_buffer, self.buffer
-                self.precision = want
-            else:
-                self.precision = want
-                self._pack_into(self.buffer, want)
+            # A render call of another thread may still hold (self.buffer, old precision) as the pair it read under the lock:
+            # the live buffer is never re-packed in another arithmetic.  The image of the wanted mode goes into the alternate
+            # buffer (the probe left it there if the parameters have not changed since) and the two are swapped.
+            if getattr(self, '_alt_version', None) != self._version:
+                self._alt_buffer = torch.empty_like(self.buffer)      # a fresh one: the old alternate may be some call's snapshot too
+                self._pack_into(self._alt_buffer, want)
+            self.buffer, self._alt_buffer = self._alt_buffer, self.buffer
+            self.precision = want
+            self._alt_version = None       # what is now the alternate holds the OTHER mode of this version at best: re-pack on use
 
     def wait_probe(self) -> Optional[float]:
         """Blocks until a probe in flight has been read and its decision taken; returns the last measured gate units."""
@@ -343,10 +368,11 @@ def mlp_points_fwd(packed: PackedMLP, points: torch.Tensor, training: bool = Fal
         raise _l.SunerfHipError('packed weights and points are on different devices')
     with packed._lock:
         packed._apply_probe()
-        if packed.auto and packed.probe_due and m > 0:
+        if packed.auto and packed.probe_due and (m > 0 or _probe_world() > 1):
             # the measured choice of the arithmetic (AUTO) needs rays: PROBE_RAYS of the points as two-sample rays o = 0, d = xyz, z = 1
+            # (a rank without points still takes part in the probe's all-reduce, with zero units)
             k = min(PROBE_RAYS, m)
-            idx = torch.linspace(0, m - 1, k, device=dev).long()
+            idx = torch.linspace(0, max(m - 1, 0), k, device=dev).long()
             sel = points[idx]
             packed.probe(torch.zeros(k, 3, device=dev), sel[:, :3].contiguous(), sel[:, 3].contiguous(), torch.ones(k, 2, device=dev), 0.0)
         weights_image, precision = packed.buffer, packed.precision
@@ -480,9 +506,10 @@ def emission_integral_bwd(raw, z_vals, rays_d, g_image=None, g_weights=None, g_a
 # device), the two-kernel dgrad + wgrad elsewhere; 'classic': always the two kernels.  The pipelined launch needs all of its
 # 256 workgroups resident at once: ranks that SHARE one GPU (the CPU-rehearsal tests) must use 'classic'.
 _backward_forced = None
-pipe_kernel_events = None                 # a list: mlp_backward appends (begin, end) events around every pipelined-kernel launch
-_pipe_ws = {}                             # (device, stream) -> (workspace, bytes)
-_pipe_checked = {}                        # workspaces whose status word has not been looked at yet
+pipe_timing = False                       # True: every pipelined launch is bracketed by library-owned HIP events (flags bit 7)
+_pipe_ws = {}                             # (device, stream) -> workspace
+_pipe_checked = {}                        # workspaces whose sticky status word has not been looked at yet
+PIPE_WS_STICKY, PIPE_WS_DEBUG = 0, 256    # include/sunerf_hip.h: fixed offsets of the sticky status block / the debug counters
 
 
 def backward_mode() -> str:
@@ -494,12 +521,34 @@ def backward_mode() -> str:
     return mode
 
 
+def _shared_device(dev) -> bool:
+    """Ranks of one process group that drive the SAME GPU cannot all keep a 256-workgroup persistent launch resident: the
+    process then uses the two-kernel backward (decided once, collectively: sunerf_hip.dist.ranks_share_a_device)."""
+    global _backward_forced
+    from . import dist as _dist
+    if _dist.ranks_share_a_device(dev, probe_group):
+        import warnings
+        warnings.warn('several ranks of the process group share one GPU: the layer-pipelined backward needs the whole device, '
+                      'this process uses the two-kernel backward (SUNERF_BACKWARD=classic)', RuntimeWarning)
+        _backward_forced = 'classic'
+        return True
+    return False
+
+
 def _env_on(name: str) -> bool:
     return os.environ.get(name, '0').lower() not in ('', '0', 'false', 'no', 'off')
 
 
 def _pipe_flags() -> int:
-    return (1 if _env_on('SUNERF_PIPE_HI_ONLY') else 0) | (2 if _env_on('SUNERF_PIPE_DEBUG') else 0)
+    return (1 if _env_on('SUNERF_PIPE_HI_ONLY') else 0) | (2 if _env_on('SUNERF_PIPE_DEBUG') else 0) | (0x80 if pipe_timing else 0)
+
+
+def pipe_kernel_time():
+    """(sum of the kernel durations in ms, number of launches) of the pipelined-backward launches issued while
+    ``ops.pipe_timing`` was set, measured by HIP events inside the C ABI on the launch stream; waits for them and forgets them."""
+    ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
+    _l.check(_l.load().sunerf_bwd_pipe_kernel_time(ctypes.byref(ms), ctypes.byref(n)), 'sunerf_bwd_pipe_kernel_time')
+    return ms.value, n.value
 
 
 def pipe_debug(dev=None):
@@ -510,7 +559,7 @@ def pipe_debug(dev=None):
     wave of the workgroups of pipeline 0 (tools/pipe_check.py prints them as a timeline)."""
     for (d, _), ws in _pipe_ws.items():
         if dev is None or d == dev:
-            return ws[-256 * 64 * 4:].view(torch.int32).reshape(8, 256, 8).cpu()
+            return ws[PIPE_WS_DEBUG:PIPE_WS_DEBUG + 256 * 64 * 4].view(torch.int32).reshape(8, 256, 8).cpu()
     return None
 
 
@@ -518,20 +567,29 @@ def _pipe_workspace(dev, nbytes: int) -> torch.Tensor:
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     ws = _pipe_ws.get(key)
     if ws is None or ws.numel() < nbytes:
+        if ws is not None and key in _pipe_checked:
+            pipe_status()          # the outgoing workspace's sticky word is looked at before it is dropped
         ws = _pipe_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws[PIPE_WS_STICKY:PIPE_WS_DEBUG].zero_()      # the sticky status block is the caller's: zeroed once, read + cleared by pipe_status
     _pipe_checked[key] = ws
     return ws
 
 
 def pipe_status(raise_on_failure: Optional[bool] = None) -> int:
-    """Status words of the pipelined backward launches since the last call (one 4-byte read per workspace; call it where the
-    step synchronises anyway).  Non-zero: a launch gave up (csrc/bwd_pipe.hip) -- its gradients were NaN, so the optimiser
-    skipped that step.  The process then switches to the two-kernel backward and says so: with a warning by default, with an
-    exception when ``SUNERF_BACKWARD=pipe`` was asked for explicitly (or ``raise_on_failure=True``)."""
+    """Worst status of ALL pipelined backward launches since the last call (one 4-byte read per workspace; call it where the
+    step synchronises anyway).  The word is sticky: every launch's reduce kernel raises it to its own status, nothing but this
+    function clears it -- a give-up of the fine model's launch is still there after the coarse model's launch on the same
+    workspace.  Non-zero: a launch gave up (csrc/bwd_pipe.hip) -- its gradients were NaN, so the optimiser skipped that step.
+    The process then switches to the two-kernel backward and says so: with a warning by default, with an exception when
+    ``SUNERF_BACKWARD=pipe`` was asked for explicitly (or ``raise_on_failure=True``)."""
     global _backward_forced
     worst = 0
     for key, ws in list(_pipe_checked.items()):
-        worst = max(worst, int(ws[:4].view(torch.int32).item()))
+        word = ws[PIPE_WS_STICKY:PIPE_WS_STICKY + 4].view(torch.int32)
+        status = int(word.item())
+        if status:
+            word.zero_()
+        worst = max(worst, status)
         del _pipe_checked[key]
     if worst:
         _backward_forced = 'classic'
@@ -560,6 +618,8 @@ def mlp_backward(packed: PackedMLP, g_raw, absmax, stash, grad_weights: Sequence
     if n > 0 and backward_mode() == 'pipe':
         with torch.cuda.device(dev):
             pipe_bytes = lib.sunerf_bwd_pipe_workspace_bytes(n, s, D, nl)     # 0: shape / device outside the pipelined kernel
+        if pipe_bytes and _shared_device(dev):
+            pipe_bytes = 0
     if not pipe_bytes:
         dz = torch.empty(lib.sunerf_dz_stash_bytes(n, s, D, nl), dtype=torch.uint8, device=dev)
         _l.call(dev, 'sunerf_mlp_dgrad', _ptr(packed.transposed()), D, nl, _ptr(g_raw), _ptr(absmax), _ptr(stash),
@@ -595,18 +655,7 @@ def mlp_backward(packed: PackedMLP, g_raw, absmax, stash, grad_weights: Sequence
         ws = _pipe_workspace(dev, pipe_bytes)
         pargs = (D, nl, packed.d_out, _ptr(packed.transposed()), _ptr(stash), _ptr(g_raw), _ptr(absmax), n, s, _ptr(ws),
                  pipe_bytes, GW, GB, int(kernel_accumulate))
-        if pipe_kernel_events is None:
-            _l.call(dev, 'sunerf_mlp_backward_pipe', *pargs, _pipe_flags(), stream)
-        else:
-            # bench.py's roofline line: the three launches (prologue, pipelined kernel, reduction) as three calls with HIP
-            # events on the launch stream around the middle one
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            _l.call(dev, 'sunerf_mlp_backward_pipe', *pargs, _pipe_flags() | 0x10, stream)
-            e0.record()
-            _l.call(dev, 'sunerf_mlp_backward_pipe', *pargs, _pipe_flags() | 0x20, stream)
-            e1.record()
-            _l.call(dev, 'sunerf_mlp_backward_pipe', *pargs, _pipe_flags() | 0x40, stream)
-            pipe_kernel_events.append((e0, e1))
+        _l.call(dev, 'sunerf_mlp_backward_pipe', *pargs, _pipe_flags(), stream)
     else:
         _l.call(dev, 'sunerf_mlp_wgrad', D, nl, packed.d_out, _ptr(packed.transposed()), _ptr(stash), _ptr(dz), _ptr(g_raw), _ptr(absmax), n, s, _ptr(ws),
                 split, GW, GB, int(kernel_accumulate), stream)

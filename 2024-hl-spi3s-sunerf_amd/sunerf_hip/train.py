@@ -148,6 +148,9 @@ class ClipAdam(torch.optim.Optimizer):
             raise ValueError('ClipAdam keeps one flat buffer: a single parameter group')
         self.max_norm = max_norm
         self.group = group
+        if group is not None:
+            from . import ops as _ops
+            _ops.probe_group = group        # the AUTO probe's MAX all-reduce runs over the same ranks as the gradient exchange
         self.reduce_single_rank = False     # tests: issue the collective even in a one-rank group (exercises RCCL on one GPU)
         # overlap: the backward of the fine model finishes before the coarse model's starts (the two graphs
         # are independent, sampling.py:120), so its slice of the bucket can be all-reduced -- asynchronously, on the

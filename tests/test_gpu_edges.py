@@ -4,6 +4,7 @@ import pytest
 import torch
 
 import sunerf_oracle as orc
+from conftest import gate_units
 
 pytestmark = pytest.mark.gpu
 
@@ -45,7 +46,7 @@ def test_ragged_shapes_vs_oracle(ops, n_rays, S):
     ref = orc.render_pass(params, o, d, t, z)
     out = ops.emission_render_fwd(packed, o.cuda(), d.cuda(), t.cuda(), z.cuda(), 1.2, want_raw=True)
     assert (out['raw'].cpu() - ref['raw']).abs().max().item() < 2e-5
-    assert ((out['image'].cpu() - ref['image']).abs().max() / ref['image'].abs().max()).item() < 1e-4
+    assert gate_units(out['image'], ref['image']) <= 1.0            # the north-star gate, per ray
     assert ((out['weights'].cpu() - ref['weights']).abs().max() / ref['weights'].abs().max()).item() < 1e-4
 
 
@@ -79,7 +80,7 @@ def test_large_batch_properties(ops):
     assert torch.equal(out2['image'], out['image'][perm])
     idx = perm[:64].cpu()
     ref = orc.render_pass(params, o.cpu()[idx], d.cpu()[idx], torch.zeros(64, 1), z.cpu()[idx])
-    assert ((out['image'].cpu()[idx] - ref['image']).abs().max() / ref['image'].abs().max()).item() < 1e-4
+    assert gate_units(out['image'][idx.cuda()], ref['image']) <= 1.0       # the north-star gate, per ray
 
 
 def test_training_batch_properties(ops):
@@ -198,7 +199,7 @@ def test_reference_default_width_512_forward(ops, n_layers, S, precision):
     ref = orc.render_pass(params, o, d, t, z)
     out = ops.emission_render_fwd(packed, o.cuda(), d.cuda(), t.cuda(), z.cuda(), 1.2, want_raw=True)
     assert (out['raw'].cpu() - ref['raw']).abs().max().item() < 2e-5
-    assert ((out['image'].cpu() - ref['image']).abs().max() / ref['image'].abs().max()).item() < 1e-4
+    assert gate_units(out['image'], ref['image']) <= 1.0            # the north-star gate, per ray
     assert ((out['weights'].cpu() - ref['weights']).abs().max() / ref['weights'].abs().max()).item() < 1e-4
 
 
@@ -216,4 +217,4 @@ def test_tiny_weights_stay_finite(ops, scale, precision):
     torch.cuda.synchronize()
     assert torch.isfinite(out['image']).all() and torch.isfinite(out['raw']).all()
     assert (out['raw'].cpu() - ref['raw']).abs().max().item() < 1e-6 + 2e-5 * scale
-    assert ((out['image'].cpu() - ref['image']).abs().max() / ref['image'].abs().max()).item() < 1e-4
+    assert gate_units(out['image'], ref['image']) <= 1.0            # the north-star gate, per ray

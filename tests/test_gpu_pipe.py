@@ -195,6 +195,57 @@ def test_a_launch_that_gives_up_leaves_nan_gradients_and_the_process_falls_back(
         assert ((W.cpu() - rW).norm() / rW.norm()).item() < 1e-3, i
 
 
+def test_a_give_up_of_the_first_launch_survives_a_second_launch_before_the_host_looks(ops, monkeypatch):
+    """Every training step runs TWO backwards on one workspace (fine model, then coarse) and pipe_status() is read once per step.
+    The launch status is cleared in front of every launch; the STICKY word in front of the control block (include/sunerf_hip.h,
+    SUNERF_PIPE_WS_STICKY) is only ever raised.  Launch 1 is made to give up (flags bit 8), launch 2 runs clean: the host still
+    sees status 2, falls back, and a clean pair afterwards reads 0."""
+    params, o, d, t, z = _case(6, 40)
+    g_image = torch.randn(o.shape[0]) * 1e-3
+    monkeypatch.setattr(ops, '_backward_forced', None)
+    monkeypatch.delenv('SUNERF_BACKWARD', raising=False)
+    dev = torch.device('cuda')
+    Ws, bs = [W.to(dev) for W, _ in params], [b.to(dev) for _, b in params]
+    packed = ops.PackedMLP(Ws, bs, precision=ops.PRECISION_EXACT)
+    fwd = ops.emission_render_fwd(packed, o.to(dev), d.to(dev), t.to(dev), z.to(dev), reg_radius=1.2, training=True)
+    ops.pipe_status(raise_on_failure=False)
+
+    def backward(flags):
+        monkeypatch.setattr(ops, '_pipe_flags', lambda: flags)
+        gW = [torch.zeros_like(W) for W in Ws]
+        gb = [torch.zeros_like(b) for b in bs]
+        ops.emission_render_bwd(packed, o.to(dev), d.to(dev), z.to(dev), fwd['raw'], fwd['stash'], g_image.to(dev), None, 2e-5, 1.2, gW, gb)
+        return gW, gb
+
+    first = backward(0x100)            # "fine model": gives up
+    second = backward(0)               # "coarse model": the same workspace, a clean launch
+    torch.cuda.synchronize()
+    assert all(torch.isnan(g).all() for g in first[0] + first[1])
+    assert all(torch.isfinite(g).all() for g in second[0] + second[1])
+    with pytest.warns(RuntimeWarning, match='pipelined backward gave up'):
+        assert ops.pipe_status() == 2                 # the first launch's failure, not the second launch's 0
+    assert ops.backward_mode() == 'classic'
+    monkeypatch.setattr(ops, '_backward_forced', None)
+    backward(0); backward(0)
+    torch.cuda.synchronize()
+    assert ops.pipe_status(raise_on_failure=False) == 0       # read-and-clear: nothing left over
+
+
+def test_pipelined_kernel_time_is_measured_inside_the_abi(ops, monkeypatch):
+    """flags bit 7: library-owned HIP events around the pipelined kernel; one C-ABI call per backward, as in the product."""
+    params, o, d, t, z = _case(6, 40)
+    g_image = torch.randn(o.shape[0]) * 1e-3
+    monkeypatch.setattr(ops, '_backward_forced', None)
+    monkeypatch.delenv('SUNERF_BACKWARD', raising=False)
+    ops.pipe_kernel_time()
+    monkeypatch.setattr(ops, 'pipe_timing', True)
+    _hip_grads(ops, 'pipe', params, o, d, t, z, g_image, 2e-5)
+    _hip_grads(ops, 'pipe', params, o, d, t, z, g_image, 2e-5)
+    ms, n = ops.pipe_kernel_time()
+    assert n == 2 and 0.0 < ms < 50.0
+    assert ops.pipe_kernel_time() == (0.0, 0)
+
+
 def test_render_from_four_threads_equals_serial_render(ops):
     """evaluation/loader.py:226-229 submits the ray batches of a frame to a ThreadPoolExecutor: same frame, bit for bit, and the
     packed-weights cache is built once."""

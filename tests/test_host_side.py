@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(sunerf_hip.EXPORTED_SYMBOLS), declared ^ set(sunerf_hip.EXPORTED_SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.sunerf_abi_version() == 7
+    assert lib.sunerf_abi_version() == 8
 
 
 def test_size_helpers(lib):
