@@ -651,6 +651,9 @@ __device__ __forceinline__ void in_stage(const PipeArgs& a, char* smem, int P, i
     }
     issue_chunk(nxt, nxt & (NBUF - 1));
     if (it < 0) continue;
+#if defined(PIPE_ABL_IN_STAGE) && PIPE_ABL_IN_STAGE
+    continue;       // timing-only knock-out (round 4): the in-layer stage keeps its protocol and its DMA, computes nothing
+#endif
     const unsigned bufA = lds0 + buf * BUF_IN + laneoff, bufB = bufA + 8 * 1024;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {

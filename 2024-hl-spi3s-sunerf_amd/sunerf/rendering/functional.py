@@ -17,24 +17,27 @@ class _MlpOnPoints(torch.autograd.Function):
         if training:
             ctx.packed, ctx.params, ctx.n_padded = packed, params, out['n_padded']
             ctx.param_meta = [(p.shape, p.device) for p in params]
-            ctx.save_for_backward(out['stash'])
+            ctx.save_for_backward(out['stash'], points)
         return out['raw'][:, :packed.d_out] if packed.d_out < 2 else out['raw']
 
     @staticmethod
     def backward(ctx, g_raw):
-        stash, = ctx.saved_tensors
+        stash, points = ctx.saved_tensors
+        if points.shape[0] != ctx.n_padded:      # the kernels work on whole 32-point chunks: zero points with zero gradient
+            points = torch.cat([points, points.new_zeros(ctx.n_padded - points.shape[0], 4)])
+        query = ('points', points)
         g = g_raw.new_zeros(ctx.n_padded, 2)
         g[:g_raw.shape[0], :g_raw.shape[1]] = g_raw
         g = g.view(ctx.n_padded // 32, 32, 2)
         absmax = g.abs().max().reshape(1).view(torch.int32)      # bit pattern of max |g_raw| (sunerf_common.h: gradient scale)
         direct = _grad_targets(ctx.params)
         if direct is not None:
-            ops.mlp_backward(ctx.packed, g, absmax, stash, direct[0], direct[1], accumulate=True)
+            ops.mlp_backward(ctx.packed, g, absmax, stash, direct[0], direct[1], accumulate=True, query=query)
             _announce(ctx.params)
             return (None,) * (2 + len(ctx.params))
         gW = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[0::2]]
         gb = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[1::2]]
-        ops.mlp_backward(ctx.packed, g, absmax, stash, gW, gb)
+        ops.mlp_backward(ctx.packed, g, absmax, stash, gW, gb, query=query)
         grads = []
         for w, b in zip(gW, gb):
             grads += [w, b]
@@ -118,7 +121,7 @@ class _EmissionPass(torch.autograd.Function):
             ctx.n_params = len(params)
             ctx.params = params
             ctx.param_meta = [(p.shape, p.device) for p in params]
-            ctx.save_for_backward(rays_o, rays_d, z_vals, out['raw'], out['stash'])
+            ctx.save_for_backward(rays_o, rays_d, z_vals, out['raw'], out['stash'], times)
         outs = [out['image'], out['weights'], out['absorption']]
         non_diff = [out['weights'], out['absorption']]
         if want_epilogues:
@@ -130,7 +133,7 @@ class _EmissionPass(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_image, g_weights, g_absorption, g_hm=None, g_am=None, g_reg=None):
-        rays_o, rays_d, z_vals, raw, stash = ctx.saved_tensors
+        rays_o, rays_d, z_vals, raw, stash, times = ctx.saved_tensors
         n, s = z_vals.shape
         if g_image is None and g_reg is None:
             return (None,) * (7 + ctx.n_params)
@@ -140,13 +143,13 @@ class _EmissionPass(torch.autograd.Function):
         direct = _grad_targets(ctx.params)
         if direct is not None:
             ops.emission_render_bwd(ctx.packed, rays_o, rays_d, z_vals, raw, stash, g_image, g_reg, 0.0, ctx.reg_radius,
-                                    direct[0], direct[1], accumulate=True)
+                                    direct[0], direct[1], accumulate=True, times=times)
             _announce(ctx.params)
             return (None,) * (7 + ctx.n_params)
         gW = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[0::2]]
         gb = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[1::2]]
         ops.emission_render_bwd(ctx.packed, rays_o, rays_d, z_vals, raw, stash, g_image, g_reg, 0.0, ctx.reg_radius,
-                                gW, gb)
+                                gW, gb, times=times)
         grads = []
         for w, b in zip(gW, gb):
             grads += [w, b]
@@ -183,13 +186,14 @@ class _MlpOnRays(torch.autograd.Function):
         if training:
             ctx.packed, ctx.params = packed, params
             ctx.param_meta = [(p.shape, p.device) for p in params]
-            ctx.save_for_backward(out['stash'])
+            ctx.save_for_backward(out['stash'], rays_o, rays_d, times, z_vals)
         ctx.d_out = packed.d_out
         return out['raw'][..., :packed.d_out] if packed.d_out < 2 else out['raw']
 
     @staticmethod
     def backward(ctx, g_raw):
-        stash, = ctx.saved_tensors
+        stash, rays_o, rays_d, times, z_vals = ctx.saved_tensors
+        query = ('rays', rays_o, rays_d, times, z_vals)
         if g_raw.shape[-1] < 2:
             g_raw = torch.cat([g_raw, torch.zeros_like(g_raw)], -1)
         g_raw = g_raw.contiguous().float()
@@ -197,12 +201,12 @@ class _MlpOnRays(torch.autograd.Function):
         absmax = g_raw.abs().max().reshape(1).view(torch.int32)
         direct = _grad_targets(ctx.params)
         if direct is not None:
-            ops.mlp_backward(ctx.packed, g_raw, absmax, stash, direct[0], direct[1], accumulate=True)
+            ops.mlp_backward(ctx.packed, g_raw, absmax, stash, direct[0], direct[1], accumulate=True, query=query)
             _announce(ctx.params)
             return (None,) * (5 + len(ctx.params))
         gW = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[0::2]]
         gb = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[1::2]]
-        ops.mlp_backward(ctx.packed, g_raw, absmax, stash, gW, gb)
+        ops.mlp_backward(ctx.packed, g_raw, absmax, stash, gW, gb, query=query)
         grads = []
         for w, b in zip(gW, gb):
             grads += [w, b]
@@ -304,7 +308,7 @@ class _DtPass(torch.autograd.Function):
             ctx.param_meta = [(p.shape, p.device) for p in params[n_la:]]
             ctx.mlp_params = params[n_la:]
             ctx.scalar_params = tuple(params[:n_la]) + (vol_c,)
-            ctx.save_for_backward(rays_o, rays_d, z_vals, wavelengths, mlp['raw'], mlp['stash'], la, vol_c.detach())
+            ctx.save_for_backward(rays_o, rays_d, z_vals, wavelengths, mlp['raw'], mlp['stash'], la, vol_c.detach(), times)
         outs = [out['image'], out['weights'], out['reg_q']]
         non_diff = [out['weights'], out['reg_q']]
         if want_epilogues:
@@ -315,7 +319,8 @@ class _DtPass(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_image, g_weights, g_q, g_hm=None, g_am=None, g_reg=None):
-        rays_o, rays_d, z_vals, wavelengths, raw, stash, la, vol_c = ctx.saved_tensors
+        rays_o, rays_d, z_vals, wavelengths, raw, stash, la, vol_c, times = ctx.saved_tensors
+        query = ('rays', rays_o, rays_d, times, z_vals)
         if g_image is None:
             g_image = torch.zeros(z_vals.shape[0], wavelengths.shape[1], dtype=torch.float32, device=z_vals.device)
         g_raw, g_la, g_vc, absmax = ops.dt_integral_bwd(raw, z_vals, rays_o, rays_d, wavelengths, ctx.tables[0], ctx.tables[1],
@@ -335,12 +340,12 @@ class _DtPass(torch.autograd.Function):
             head = (None,) * 10 + (g_vc.reshape(()),) + tuple(g_la[i] for i in range(g_la.shape[0]))
         direct = _grad_targets(ctx.mlp_params)
         if direct is not None:
-            ops.mlp_backward(ctx.packed, g_raw, absmax, stash, direct[0], direct[1], accumulate=True)
+            ops.mlp_backward(ctx.packed, g_raw, absmax, stash, direct[0], direct[1], accumulate=True, query=query)
             _announce(ctx.mlp_params)
             return head + (None,) * len(ctx.mlp_params)
         gW = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[0::2]]
         gb = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.param_meta[1::2]]
-        ops.mlp_backward(ctx.packed, g_raw, absmax, stash, gW, gb)
+        ops.mlp_backward(ctx.packed, g_raw, absmax, stash, gW, gb, query=query)
         grads = []
         for w, b in zip(gW, gb):
             grads += [w, b]

@@ -30,6 +30,8 @@ class GradBucket:
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        if dev.type == 'cuda':
+            ranks_share_a_device(dev)          # (collective, once: decides pipelined vs two-kernel backward for shared cards)
         off = 0
         self.views = []
         for p in self.params:
@@ -90,14 +92,21 @@ def ranks_share_a_device(dev, group=None) -> bool:
     """Collective (every rank of ``group`` must call it at the same point): do two ranks drive the same physical GPU?  The
     layer-pipelined backward needs all 256 of its workgroups resident at once, each filling a whole CU; ranks that share a card
     (CPU-style rehearsals of the multi-rank path on one GPU) would starve each other's launches into their time-outs, so they
-    take the two-kernel backward.  One all_gather_object per (device, group), cached."""
+    take the two-kernel backward.  One all_gather_object per device, cached; called where every rank passes exactly once --
+    the construction of the optimiser / gradient bucket (``ClipAdam``, ``GradBucket``)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
         return False
-    key = (str(dev), id(group))
+    key = str(torch.device(dev))
     if key not in _shared_cache:
         mine = device_identity(dev)
         everyone = [None] * dist.get_world_size(group)
         dist.all_gather_object(everyone, mine, group=group)
         _shared_cache[key] = any_shared(everyone)
     return _shared_cache[key]
+
+
+def shared_device_known(dev) -> bool:
+    """The cached answer of :func:`ranks_share_a_device` for ``dev`` (False when nobody has asked): what the backward consults --
+    it must not start a collective of its own, since ranks may take different backward paths for batches of different sizes."""
+    return _shared_cache.get(str(torch.device(dev)), False)
 

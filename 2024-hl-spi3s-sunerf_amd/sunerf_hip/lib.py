@@ -54,6 +54,12 @@ _SIGNATURES = {
                                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
                                                  ctypes.c_int, c_void]),
     'sunerf_bwd_pipe_kernel_time': (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
+    'sunerf_mlp_backward_exact_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    'sunerf_mlp_backward_exact': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                                  ctypes.c_int64, ctypes.c_int, c_f32p, c_void, ctypes.c_size_t,
+                                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
+                                                  c_void]),
     'sunerf_dt_integral_fwd': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, c_f32p, c_f32p, c_f32p,
                                                c_f32p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                                ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,

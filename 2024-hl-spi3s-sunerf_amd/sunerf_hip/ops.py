@@ -449,10 +449,11 @@ def wgrad_split(n_linear: int, n_cus: int = 256, d_filter: int = 256) -> int:
 
 def emission_render_bwd(packed: PackedMLP, rays_o, rays_d, z_vals, raw, stash, g_image, g_reg, g_reg_const: float,
                         reg_radius: float, grad_weights: Sequence[torch.Tensor], grad_biases: Sequence[torch.Tensor],
-                        accumulate: bool = False):
+                        accumulate: bool = False, times=None):
     """Backward of one render pass: fills (or accumulates into) ``grad_weights[i]`` / ``grad_biases[i]`` (nn.Linear
     layouts) from the gradient w.r.t. the 'image' output (N,) or (N,1) and the 'regularization' output
-    (``g_reg`` (N,S) tensor or None + the constant ``g_reg_const``)."""
+    (``g_reg`` (N,S) tensor or None + the constant ``g_reg_const``).  ``times`` (N,): the forward's time coordinate -- with it
+    the small-batch fp32 backward can recompute the activations (``mlp_backward(query=...)``); without it the fp16 kernels run."""
     lib = _l.load()
     n, s = z_vals.shape
     dev = z_vals.device
@@ -469,7 +470,8 @@ def emission_render_bwd(packed: PackedMLP, rays_o, rays_d, z_vals, raw, stash, g
     stream = _stream(dev)
     _l.call(dev, 'sunerf_emission_integral_bwd', _ptr(raw), _ptr(z_vals), _ptr(rays_o), _ptr(rays_d), _ptr(g_image),
             _ptr(g_reg), None, None, float(g_reg_const), float(reg_radius), n, s, _ptr(g_raw), _ptr(absmax), stream)
-    mlp_backward(packed, g_raw, absmax, stash, grad_weights, grad_biases, accumulate)
+    mlp_backward(packed, g_raw, absmax, stash, grad_weights, grad_biases, accumulate,
+                 query=None if times is None else ('rays', rays_o, rays_d, times, z_vals))
     return g_raw
 
 
@@ -523,10 +525,11 @@ def backward_mode() -> str:
 
 def _shared_device(dev) -> bool:
     """Ranks of one process group that drive the SAME GPU cannot all keep a 256-workgroup persistent launch resident: the
-    process then uses the two-kernel backward (decided once, collectively: sunerf_hip.dist.ranks_share_a_device)."""
+    process then uses the two-kernel backward (decided once, collectively, when the optimiser / gradient bucket is built:
+    sunerf_hip.dist.ranks_share_a_device; here only the cached answer is read -- no collective inside a backward)."""
     global _backward_forced
     from . import dist as _dist
-    if _dist.ranks_share_a_device(dev, probe_group):
+    if _dist.shared_device_known(dev):
         import warnings
         warnings.warn('several ranks of the process group share one GPU: the layer-pipelined backward needs the whole device, '
                       'this process uses the two-kernel backward (SUNERF_BACKWARD=classic)', RuntimeWarning)
@@ -539,8 +542,74 @@ def _env_on(name: str) -> bool:
     return os.environ.get(name, '0').lower() not in ('', '0', 'false', 'no', 'off')
 
 
+def pipe_w_mode() -> str:
+    """Precision of W^T in the pipelined backward's data gradient: 'auto' (default: a single fp16 W^T while a measured probe
+    allows it, fp16 head + remainder otherwise -- see _pipe_w_probe), 'hi' (SUNERF_PIPE_HI_ONLY=1), 'hilo' (=0)."""
+    v = os.environ.get('SUNERF_PIPE_HI_ONLY', 'auto').strip().lower()
+    if v in ('', 'auto'):
+        return 'auto'
+    return 'hilo' if v in ('0', 'false', 'no', 'off') else 'hi'
+
+
 def _pipe_flags() -> int:
-    return (1 if _env_on('SUNERF_PIPE_HI_ONLY') else 0) | (2 if _env_on('SUNERF_PIPE_DEBUG') else 0) | (0x80 if pipe_timing else 0)
+    return (1 if pipe_w_mode() == 'hi' else 0) | (2 if _env_on('SUNERF_PIPE_DEBUG') else 0) | (0x80 if pipe_timing else 0)
+
+
+# ---- single or split W^T in the pipelined backward: chosen by measurement, like the forward arithmetic -----------------------
+# The data-gradient waves multiply dZ by W^T as fp16 head + fp16 remainder (32 matrix instructions per chunk) or by the head
+# alone (16: the kernel -5.7 %, the training step -3.3 %, tools/experiments/r4_pipe_ab.sh).  The head alone is a SYSTEMATIC
+# perturbation of the weights (2^-12 per element, the same for every sample), so its effect on the weight gradients does not
+# average over the batch -- and for the same reason it can be measured on a few rays: the relative difference between the two
+# arithmetics on the first 64 rays of a batch predicts the difference on 8192 rays within 2 %
+# (tools/experiments/r4_hi_only_accuracy.py: 5.2e-4 at default initialisation, 5.1e-4 with hidden weights x 2, 7.5e-4 at x 3,
+# 9.0e-4 at x 4, against fp32 gradients: head + remainder 2.5 ... 3.4e-4 / 4.9e-4 / 7.8e-4, head alone 5.4 ... 6.0e-4 / 9.1e-4 /
+# 1.0e-3).  Every PROBE_EVERY-th parameter version (and at the first pipelined backward of a model) both arithmetics run on
+# those rays; the head alone is used while the worst weight tensor differs by at most PIPE_W_LIMIT, which keeps the gradients
+# within ~0.6 of SURVEY 8d's 1e-3.  No collective: under data parallelism every rank decides for itself (the all-reduced
+# gradient, and with it every replica, is the same on all ranks whichever arithmetic produced a rank's share).
+PIPE_W_PROBE_RAYS = 64
+PIPE_W_LIMIT = 6e-4
+
+
+def _pipe_w_probe(packed, call_prefix):
+    """Runs the pipelined backward on the first PIPE_W_PROBE_RAYS rays in both arithmetics into scratch gradients and leaves the
+    worst relative difference of a weight tensor in a pinned host word behind an event (read at once for the first probe)."""
+    dev = packed.device
+    if getattr(packed, '_pipe_probe_bufs', None) is None:
+        f32 = dict(dtype=torch.float32, device=dev)
+        packed._pipe_probe_bufs = [([torch.empty(ws, **f32) for ws, _ in packed.kernel_shapes()],
+                                    [torch.empty(bs, **f32) for _, bs in packed.kernel_shapes()]) for _ in range(2)]
+    nl = packed.n_linear
+    for hi_only, (gW, gb) in zip((0, 1), packed._pipe_probe_bufs):
+        GW = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gW])
+        GB = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gb])
+        call_prefix(GW, GB, hi_only)
+    (a, _), (b, _) = packed._pipe_probe_bufs
+    diff = torch._foreach_norm(torch._foreach_sub(b, a))
+    base = torch._foreach_norm(a)
+    units = torch.nan_to_num((torch.stack(diff) / torch.stack(base)).max().reshape(1), nan=float('inf'))
+    host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+    host.copy_(units, non_blocking=True)
+    event = torch.cuda.Event()
+    event.record(torch.cuda.current_stream(dev))
+    first = getattr(packed, 'pipe_w_probe', None) is None
+    packed._pipe_w_pending = (host, event)
+    packed._pipe_probe_version = packed._version
+    _pipe_w_apply(packed, block=first or not PROBE_ASYNC)
+
+
+def _pipe_w_apply(packed, block: bool = False):
+    pending = getattr(packed, '_pipe_w_pending', None)
+    if pending is None:
+        return
+    host, event = pending
+    if block:
+        event.synchronize()
+    elif not event.query():
+        return
+    packed._pipe_w_pending = None
+    packed.pipe_w_probe = float(host[0])
+    packed.pipe_hi_only = packed.pipe_w_probe <= PIPE_W_LIMIT
 
 
 def pipe_kernel_time():
@@ -605,22 +674,80 @@ def pipe_status(raise_on_failure: Optional[bool] = None) -> int:
     return worst
 
 
+# ---- small batches: the reference's arithmetic (csrc/bwd_exact.hip) ---------------------------------------------------------
+# The fp16 backward kernels carry ~2^-12 of relative rounding error per term of a gradient sum (dZ, cos, H are single fp16
+# operands).  A training batch averages that away (every tensor within 1e-3 of the fp32 oracle from ~1e4 samples on); a batch of a
+# few hundred samples whose bias sums cancel to a few per cent of their terms does not (tests/tools/bias_conditioning.py).  Up to
+# EXACT_BACKWARD_SAMPLES samples per call -- where the fp16 kernels are launch-latency-bound anyway -- the backward therefore
+# recomputes the activations and runs the chain in fp32.  SUNERF_EXACT_BACKWARD_SAMPLES overrides the limit (0: never); a
+# backward kernel asked for BY NAME (SUNERF_BACKWARD, tests forcing a mode) is always honoured.
+EXACT_BACKWARD_SAMPLES = 4096
+
+
+def exact_backward_limit() -> int:
+    v = os.environ.get('SUNERF_EXACT_BACKWARD_SAMPLES', '').strip()
+    return EXACT_BACKWARD_SAMPLES if v == '' else max(0, int(v))
+
+
+def _use_exact_backward(n_samples: int, query) -> bool:
+    if query is None or n_samples <= 0:
+        return False
+    if _backward_forced is not None or os.environ.get('SUNERF_BACKWARD', '').strip():
+        return False
+    return n_samples <= exact_backward_limit()
+
+
+_exact_ws = {}          # (device, stream) -> workspace of the fp32 backward
+
+
+def _mlp_backward_exact(packed: PackedMLP, g_raw, query, grad_weights, grad_biases, accumulate: bool):
+    lib = _l.load()
+    dev = g_raw.device
+    n, s = g_raw.shape[0], g_raw.shape[1]
+    ws_, bs_ = packed._keepalive          # fp32 parameters of the kernel shapes (the padded copies for padded models)
+    nl = packed.n_linear
+    nbytes = lib.sunerf_mlp_backward_exact_workspace_bytes(n * s, packed.d_filter, nl)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _exact_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _exact_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    W = (ctypes.c_void_p * nl)(*[w.data_ptr() for w in ws_])
+    B = (ctypes.c_void_p * nl)(*[b.data_ptr() for b in bs_])
+    GW = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grad_weights])
+    GB = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grad_biases])
+    if query[0] == 'rays':
+        _, o, d, t, z = query
+        o, d = _dev(o, 'rays_o', (n, 3)), _dev(d, 'rays_d', (n, 3))
+        t, z = _dev(t.reshape(-1), 'times', (n,)), _dev(z, 'z_vals', (n, s))
+        args = (_ptr(o), _ptr(d), _ptr(t), _ptr(z), None)
+    else:
+        pts = _dev(query[1], 'points', (n * s, 4))
+        args = (None, None, None, None, _ptr(pts))
+    g = g_raw if g_raw.shape[-1] == packed.d_out else g_raw[..., :packed.d_out]       # (N, S, d_out), densely packed
+    g = _dev(g, 'g_raw')
+    _l.call(dev, 'sunerf_mlp_backward_exact', W, B, nl, packed.d_filter, packed.d_out, *args, n, s, _ptr(g),
+            _ptr(ws), nbytes, GW, GB, int(accumulate), _stream(dev))
+
+
 def mlp_backward(packed: PackedMLP, g_raw, absmax, stash, grad_weights: Sequence[torch.Tensor],
-                 grad_biases: Sequence[torch.Tensor], accumulate: bool = False):
+                 grad_biases: Sequence[torch.Tensor], accumulate: bool = False, query=None):
     """dgrad + wgrad of the sine MLP from the gradient w.r.t. its raw output (N,S,2): fills / accumulates the nn.Linear
-    gradients.  ``absmax``: 4-byte device scalar with the bit pattern of max |g_raw| (written by the integral backward)."""
+    gradients.  ``absmax``: 4-byte device scalar with the bit pattern of max |g_raw| (written by the integral backward).
+    ``query``: what the forward was evaluated on -- ``('rays', rays_o, rays_d, times, z_vals)`` or ``('points', points (N*S, 4))``;
+    given it, batches of at most ``exact_backward_limit()`` samples take the fp32 backward (csrc/bwd_exact.hip)."""
     lib = _l.load()
     n, s = g_raw.shape[0], g_raw.shape[1]
     dev = g_raw.device
     D, nl = packed.d_filter, packed.n_linear
     stream = _stream(dev)
+    exact = _use_exact_backward(n * s, query)
     pipe_bytes = 0
-    if n > 0 and backward_mode() == 'pipe':
+    if n > 0 and not exact and backward_mode() == 'pipe':
         with torch.cuda.device(dev):
             pipe_bytes = lib.sunerf_bwd_pipe_workspace_bytes(n, s, D, nl)     # 0: shape / device outside the pipelined kernel
         if pipe_bytes and _shared_device(dev):
             pipe_bytes = 0
-    if not pipe_bytes:
+    if not pipe_bytes and not exact:
         dz = torch.empty(lib.sunerf_dz_stash_bytes(n, s, D, nl), dtype=torch.uint8, device=dev)
         _l.call(dev, 'sunerf_mlp_dgrad', _ptr(packed.transposed()), D, nl, _ptr(g_raw), _ptr(absmax), _ptr(stash),
                 _ptr(dz), n, s, stream)
@@ -651,11 +778,28 @@ def mlp_backward(packed: PackedMLP, g_raw, absmax, stash, grad_weights: Sequence
             raise ValueError(f'grad buffer {i} has the wrong shape / layout')
     GW = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grad_weights])
     GB = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grad_biases])
-    if pipe_bytes:
+    if exact:
+        _mlp_backward_exact(packed, g_raw, query, grad_weights, grad_biases, kernel_accumulate)
+    elif pipe_bytes:
         ws = _pipe_workspace(dev, pipe_bytes)
+        flags = _pipe_flags()
+        if pipe_w_mode() == 'auto':
+            with packed._lock:
+                due = (getattr(packed, '_pipe_probe_version', None) is None
+                       or packed._version - packed._pipe_probe_version >= PROBE_EVERY)
+                if due and n >= PIPE_W_PROBE_RAYS and getattr(packed, '_pipe_w_pending', None) is None:
+                    k = PIPE_W_PROBE_RAYS
+
+                    def call_prefix(gw, gb, hi_only):      # the first k rays: a prefix of g_raw and of the (ray-major) stash
+                        _l.call(dev, 'sunerf_mlp_backward_pipe', D, nl, packed.d_out, _ptr(packed.transposed()), _ptr(stash),
+                                _ptr(g_raw), _ptr(absmax), k, s, _ptr(ws), pipe_bytes, gw, gb, 0, (flags & ~0x81) | hi_only, stream)
+                    _pipe_w_probe(packed, call_prefix)
+                _pipe_w_apply(packed)
+                if getattr(packed, 'pipe_hi_only', False):
+                    flags |= 1
         pargs = (D, nl, packed.d_out, _ptr(packed.transposed()), _ptr(stash), _ptr(g_raw), _ptr(absmax), n, s, _ptr(ws),
                  pipe_bytes, GW, GB, int(kernel_accumulate))
-        _l.call(dev, 'sunerf_mlp_backward_pipe', *pargs, _pipe_flags(), stream)
+        _l.call(dev, 'sunerf_mlp_backward_pipe', *pargs, flags, stream)
     else:
         _l.call(dev, 'sunerf_mlp_wgrad', D, nl, packed.d_out, _ptr(packed.transposed()), _ptr(stash), _ptr(dz), _ptr(g_raw), _ptr(absmax), n, s, _ptr(ws),
                 split, GW, GB, int(kernel_accumulate), stream)

@@ -164,6 +164,8 @@ class ClipAdam(torch.optim.Optimizer):
         dev = self._params[0].device
         if dev.type != 'cuda' or any(p.device != dev or p.dtype != torch.float32 for p in self._params):
             raise _l.SunerfHipError('ClipAdam needs float32 parameters on one ROCm device')
+        from . import dist as _sdist
+        _sdist.ranks_share_a_device(dev, group)      # (collective, once per device: ranks sharing a card take the two-kernel backward)
         n = sum(p.numel() for p in self._params)
         self.n_params = n
         self.flat_params = torch.empty(n, dtype=torch.float32, device=dev)

@@ -342,6 +342,9 @@ def main():
     elapsed = el.item()
     mode_used = ops.PRECISION_NAMES[model.packed().precision]       # what AUTO settled on (fast unless the probe objected)
     probe_units = model.packed().last_probe
+    # W^T of the pipelined backward's data gradient: a single fp16 image while the measured probe allows it (ops._pipe_w_probe)
+    pipe_single_w = bool(getattr(model.packed(), 'pipe_hi_only', False)) or ops.pipe_w_mode() == 'hi'
+    pipe_w_probe = getattr(model.packed(), 'pipe_w_probe', None)
 
     extras = {}
     if args.mode == 'train' and not args.no_small_batch and n_local >= 3072:
@@ -403,13 +406,18 @@ def main():
         bwd_kernel = None
         if bwd_ms:
             bwd_achieved = rays_per_step * args.samples * flops_bwd(D_FILTER) / (bwd_ms * 1e-3) / 1e12
-            bwd_kernel = {'kernel': 'bwd_pipe_kernel<false>' if not os.environ.get('SUNERF_PIPE_HI_ONLY') else 'bwd_pipe_kernel<true>',
+            bwd_kernel = {'kernel': 'bwd_pipe_kernel<true>' if pipe_single_w else 'bwd_pipe_kernel<false>',
                           'kernel_ms_hip_events': bwd_ms, 'launches_timed': bwd_launches, 'achieved': bwd_achieved,
                           'frac': bwd_achieved / PEAK_F16_DENSE_TFLOPS, 'flops_per_sample': flops_bwd(D_FILTER),
-                          'executed_frac': bwd_achieved * (3 * 7 * D_FILTER * D_FILTER + 2 * ENC * D_FILTER) * 2 / flops_bwd(D_FILTER)
-                                           / PEAK_F16_DENSE_TFLOPS,
-                          'what': 'dgrad (W^T as fp16 head + remainder: two products) + wgrad of all layers but the out layer in one '
-                                  'persistent launch; the out layer and dZ of the last activation layer come from a 1.2 ms prologue kernel'}
+                          'executed_frac': bwd_achieved * ((2 if pipe_single_w else 3) * 7 * D_FILTER * D_FILTER + 2 * ENC * D_FILTER) * 2
+                                           / flops_bwd(D_FILTER) / PEAK_F16_DENSE_TFLOPS,
+                          'what': ('dgrad (W^T as ' + ('a single fp16 image: the measured policy of ops._pipe_w_probe allows it' if pipe_single_w
+                                                      else 'fp16 head + remainder: two products')
+                                   + ') + wgrad of all layers but the out layer in one persistent launch; the out layer and dZ of the '
+                                   'last activation layer come from a 1.2 ms prologue kernel'),
+                          'weight_precision': f"{ops.pipe_w_mode()} -> {'single fp16' if pipe_single_w else 'fp16 head + remainder'}"
+                                              + (f' (probe: worst weight tensor differs by {pipe_w_probe:.2e}, limit {ops.PIPE_W_LIMIT:.0e})'
+                                                 if pipe_w_probe is not None else '')}
         step_ms = elapsed / args.steps * 1e3
         step_achieved = rays_per_step * args.samples * flops_step / (step_ms * 1e-3) / 1e12
         # matrix-pipe work of the forward per algorithmic flop: EXACT 3 fp16 products; FAST 1 fp16 product + two 64-deep
@@ -478,7 +486,7 @@ def main():
                                                              'flops_per_sample', 'executed_frac', 'arithmetic_ceiling_frac',
                                                              'frac_of_arithmetic_ceiling', 'traffic', 'traffic_source')}
                 line['roofline'].update({k: bwd_kernel[k] for k in ('kernel', 'kernel_ms_hip_events', 'launches_timed', 'achieved', 'frac',
-                                                                    'flops_per_sample', 'executed_frac')})
+                                                                    'flops_per_sample', 'executed_frac', 'weight_precision')})
                 line['roofline'].pop('frac_of_f32_mfma_peak')      # (an fp16-operand kernel: only the f16 peak is its scale)
                 line['roofline']['what'] = bwd_kernel['what']
                 line['roofline'].pop('arithmetic_ceiling_frac'); line['roofline'].pop('frac_of_arithmetic_ceiling')

@@ -210,6 +210,26 @@ int sunerf_mlp_backward_pipe(int d_filter, int n_linear, int d_out, const void* 
                              int accumulate, int flags, void* stream);
 int sunerf_bwd_pipe_kernel_time(double* total_ms, int* launches);
 
+/* The same gradients in the REFERENCE's arithmetic, for small batches: every product and sum in fp32 (fp32-input MFMA), the
+ * forward activations recomputed in fp32 from the query points (the fp16 activation stash is not read).  Replaces
+ * torch.autograd over sunerf/model/model.py:44-57 + 123-132 where the fp16 kernels above are not the right tool: their
+ * operands (dZ, cos, H) carry 2^-12 of relative rounding error per term, which a training batch averages away but a sum over a
+ * few hundred samples that cancels to a few per cent of its terms does not (bias gradients of tiny batches: 2e-3 ... 3e-2).
+ *   weights / biases          : host arrays of n_linear DEVICE pointers, nn.Linear layouts of the kernel shapes
+ *                               ([d_filter][84], [d_filter][d_filter] ..., [d_out][d_filter]; fp32)
+ *   query points              : either rays (rays_o, rays_d (N,3), times (N), z_vals (N,S); points = o + d z as sampling.py:100
+ *                               forms them) or `points` (N*S, 4) given explicitly (then the ray arguments may be NULL)
+ *   g_raw (N,S,d_out)         : gradient w.r.t. the raw MLP output (no scaling convention: plain fp32)
+ *   workspace                 : sunerf_mlp_backward_exact_workspace_bytes(N*S, d_filter, n_linear) bytes
+ *   grad_weights / grad_biases: as sunerf_mlp_wgrad (overwritten, or added to when accumulate != 0)
+ * Cost ~ 0.25 us per sample of an 8 x 256 network: meant for <= a few thousand samples (sunerf_hip/ops.py picks it by count). */
+size_t sunerf_mlp_backward_exact_workspace_bytes(int64_t n_points, int d_filter, int n_linear);
+int sunerf_mlp_backward_exact(const float* const* weights_host, const float* const* biases_host, int n_linear, int d_filter,
+                              int d_out, const float* rays_o, const float* rays_d, const float* times, const float* z_vals,
+                              const float* points, int64_t n_rays, int n_samples, const float* g_raw, void* workspace,
+                              size_t workspace_bytes, float* const* grad_weights_host, float* const* grad_biases_host,
+                              int accumulate, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Density / temperature head (run_density_temperature.py path).
  * Replaces DensityTemperatureRadiativeTransfer.raw2outputs / regularization, density_temperature.py:192-274, the base

@@ -6,6 +6,7 @@ import pytest
 import torch
 
 import sunerf_oracle as orc
+from conftest import fp16_chain_bias_bounds
 
 pytestmark = pytest.mark.gpu
 
@@ -162,14 +163,28 @@ def test_backward_with_scaled_up_hidden_weights(ops, scale):
                             gW, gb)
     torch.cuda.synchronize()
     growth = ref_grads[0][1].abs().max() / ref_grads[-1][1].abs().max()      # |db_0| / |db_out|: the chain's amplification
+    bias_bounds = fp16_chain_bias_bounds(params, o, d, t, z, ref_graw)
     worst = 0.
     for i, ((rW, rb), W, b) in enumerate(zip(ref_grads, gW, gb)):
         assert torch.isfinite(W).all() and torch.isfinite(b).all(), i
         eW, eb = ((W.cpu() - rW).norm() / rW.norm()).item(), ((b.cpu() - rb).norm() / rb.norm()).item()
         worst = max(worst, eW, eb)
-        # the oracle's own fp32 autograd is ill-conditioned at x 4 (its forward noise is 0.1 gate units there): 2e-3
-        assert eW < (1e-3 if scale <= 2 else 2e-3) and eb < (1e-3 if scale <= 2 else 2e-3), (i, eW, eb)
-    print(f'hidden x {scale:g}: gradient growth out -> in {growth.item():.1f} x, worst relative L2 error {worst:.2e}')
+        # fp16 kernels (no query points given above).  SURVEY 8d's 1e-3 for every weight tensor; a bias sum gets what single fp16
+        # operands allow for ITS conditioning (conftest.fp16_chain_bias_bounds: 1e-3 unless the sum cancels) -- at x 4 the chain
+        # amplifies 2^8.4 and the weight tensors keep 1e-3 only with the margin the oracle's own ill-conditioning leaves: 2e-3
+        assert eW < (1e-3 if scale <= 2 else 2e-3), (i, eW)
+        assert eb < max(bias_bounds[i][1], 1e-3 if scale <= 2 else 2e-3), (i, eb, bias_bounds[i])
+    print(f'hidden x {scale:g}: gradient growth out -> in {growth.item():.1f} x, fp16 kernels worst relative L2 error {worst:.2e} '
+          f'(bias kappa {max(k for k, _ in bias_bounds):.1f})')
+    # the product's default for a batch of this size (576 samples): the fp32 backward -- every tensor, biases included, at 1e-3
+    gW, gb = [torch.full_like(W, float('nan')) for W in Ws], [torch.full_like(b, float('nan')) for b in bs]
+    ops.emission_render_bwd(packed, o.to(dev), d.to(dev), z.to(dev), fwd['raw'], fwd['stash'], g_image.to(dev), None, 2e-5, 1.2,
+                            gW, gb, times=t.to(dev))
+    torch.cuda.synchronize()
+    worst32 = max(max(((W.cpu() - rW).norm() / rW.norm()).item(), ((b.cpu() - rb).norm() / rb.norm()).item())
+                  for (rW, rb), W, b in zip(ref_grads, gW, gb))
+    print(f'hidden x {scale:g}: default path (fp32 backward) worst relative L2 error {worst32:.2e}')
+    assert worst32 < 1e-3
 
 
 def test_backward_saturates_instead_of_overflowing(ops):
@@ -222,7 +237,9 @@ def test_every_tensor_keeps_its_relative_accuracy_in_deep_attenuating_and_amplif
     """The data gradient changes scale by the layer's gain every time it passes a layer (x 0.41 at default initialisation,
     x 0.1 with hidden weights x 0.25: 1e-7 after seven layers, far inside fp16's subnormals -- a randomised sweep found 2e-2
     on the first layers' gradients there).  sunerf_pack_mlp_t's per-layer powers of two keep the chain at the scale of g_raw:
-    EVERY tensor, first layer included, within 1e-3 (weights) / 2e-3 (biases: plain sums, no averaging factor) of the oracle."""
+    EVERY weight tensor, first layer included, within 1e-3 of the oracle and every bias within what its conditioning allows
+    single fp16 operands (conftest.fp16_chain_bias_bounds: 1e-3 unless the sum cancels; kappa printed) -- and, through the
+    product's default path for a batch of this size (the fp32 backward), every tensor within 1e-3."""
     params = orc.init_params(d_filter=d_filter, n_layers=n_layers, seed=1019)
     params = [((W * scale) if 0 < i < len(params) - 1 else W, b) for i, (W, b) in enumerate(params)]
     o, d = orc.synthetic_rays(5)
@@ -232,13 +249,24 @@ def test_every_tensor_keeps_its_relative_accuracy_in_deep_attenuating_and_amplif
     leaves = [(W.clone().requires_grad_(True), b.clone().requires_grad_(True)) for W, b in params]
     ref = orc.render_pass(leaves, o, d, t, z)
     g_img = torch.randn(17, 1, generator=torch.Generator().manual_seed(3))
+    ref['raw'].retain_grad()
     (ref['image'] * g_img).sum().backward()
+    bounds = fp16_chain_bias_bounds(params, o, d, t, z, ref['raw'].grad)
     pk = ops.PackedMLP([W.cuda() for W, _ in params], [b.cuda() for _, b in params])
     out = ops.emission_render_fwd(pk, o.cuda(), d.cuda(), t.cuda(), z.cuda(), 1.2, training=True)
     gW = [torch.empty_like(W).cuda() for W, _ in params]
     gb = [torch.empty_like(b).cuda() for _, b in params]
     ops.emission_render_bwd(pk, o.cuda(), d.cuda(), z.cuda(), out['raw'], out['stash'], g_img.cuda(), None, 0.0, 1.2, gW, gb)
     worst_w = max(((g.cpu() - W.grad).norm() / W.grad.norm()).item() for (W, _), g in zip(leaves, gW))
-    worst_b = max(((g.cpu() - b.grad).norm() / b.grad.norm()).item() for (_, b), g in zip(leaves, gb))
-    print(f'hidden x {scale:g}, {n_layers} x {d_filter}: worst weight tensor {worst_w:.2e}, worst bias tensor {worst_b:.2e}')
-    assert worst_w <= 1e-3 and worst_b <= 2e-3
+    e_b = [((g.cpu() - b.grad).norm() / b.grad.norm()).item() for (_, b), g in zip(leaves, gb)]
+    print(f'hidden x {scale:g}, {n_layers} x {d_filter}, fp16 kernels: worst weight tensor {worst_w:.2e}, biases '
+          + ' '.join(f'{e:.1e}/{bd:.1e}(k {k:.1f})' for e, (k, bd) in zip(e_b, bounds)))
+    assert worst_w <= 1e-3
+    for l, (e, (_, bd)) in enumerate(zip(e_b, bounds)):
+        assert e <= bd, (l, e, bd)
+    ops.emission_render_bwd(pk, o.cuda(), d.cuda(), z.cuda(), out['raw'], out['stash'], g_img.cuda(), None, 0.0, 1.2, gW, gb,
+                            times=t.cuda())          # 2176 samples: the default path is the fp32 backward
+    worst32 = max(max(((g.cpu() - W.grad).norm() / W.grad.norm()).item() for (W, _), g in zip(leaves, gW)),
+                  max(((g.cpu() - b.grad).norm() / b.grad.norm()).item() for (_, b), g in zip(leaves, gb)))
+    print(f'hidden x {scale:g}, {n_layers} x {d_filter}, default path: worst tensor {worst32:.2e}')
+    assert worst32 <= 1e-3

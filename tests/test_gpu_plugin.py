@@ -176,7 +176,7 @@ def test_module_call_on_free_standing_points_is_differentiable():
     (orc.mlp_forward(params, g['x']) * probe.cpu()).sum().backward()
     lin = net.linears()
     for (W, b), layer in zip(params, lin):
-        for ref, got, bound in ((W.grad, layer.weight.grad, 1e-3), (b.grad, layer.bias.grad, 2e-3)):   # 256 points: plain sums
+        for ref, got, bound in ((W.grad, layer.weight.grad, 1e-3), (b.grad, layer.bias.grad, 1e-3)):   # (256 points: the fp32 backward)
             assert ((got.cpu() - ref).norm() / ref.norm()).item() <= bound
     with torch.no_grad():
         plain = net(x)['inferences']

@@ -95,6 +95,13 @@ def test_environment_switches(monkeypatch):
     assert ops._pipe_flags() == 0
     monkeypatch.setenv('SUNERF_PIPE_DEBUG', '1')
     assert ops._pipe_flags() == 2
+    # W^T precision of the pipelined backward: unset = measured policy (no flag bit: the policy sets it per launch), 1 / 0 force
+    monkeypatch.delenv('SUNERF_PIPE_HI_ONLY')
+    assert ops.pipe_w_mode() == 'auto' and ops._pipe_flags() == 2
+    monkeypatch.setenv('SUNERF_PIPE_HI_ONLY', '1')
+    assert ops.pipe_w_mode() == 'hi' and ops._pipe_flags() == 3
+    monkeypatch.setenv('SUNERF_PIPE_HI_ONLY', '0')
+    assert ops.pipe_w_mode() == 'hilo' and ops._pipe_flags() == 2
 
 
 def test_bucket_registry_is_keyed_by_identity_and_holds_no_strong_references():

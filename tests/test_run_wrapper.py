@@ -45,7 +45,7 @@ def test_shared_device_rule():
     from sunerf_hip import dist as sd
     assert not sd.any_shared([('a', 'gpu0'), ('a', 'gpu1'), ('b', 'gpu0')])
     assert sd.any_shared([('a', 'gpu0'), ('a', 'gpu1'), ('a', 'gpu0')])
-    assert not sd.ranks_share_a_device('cuda:0')          # no process group: never
+    assert not sd.ranks_share_a_device('cuda:0') and not sd.shared_device_known('cuda:0')          # no process group: never
 
 
 def test_wrapper_runs_an_unchanged_script_in_every_rank(tmp_path):

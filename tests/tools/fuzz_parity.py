@@ -1,11 +1,13 @@
 """Randomised parity sweep of the render pass (forward AND parameter gradients) against the CPU oracle: random ray counts,
-sample counts (ragged: not multiples of 32), widths, depths, weight scales and both forward arithmetics.  Development aid, run
-on the GPU box:  python tools/fuzz_parity.py [n_cases] [seed].  Prints one line per case; exits 1 if any case is outside the
-gates (raw 5e-5 abs FAST / 1e-5 EXACT at O(1) outputs, image / weights 1e-4 of the tensor scale, gradients 1.5e-3 rel L2).
-Known: with seed 1, cases 23, 37 and 57 (34 ... 1100 samples in all) miss the gradient gate on BIAS tensors only (FUZZ_VERBOSE=<case>
-prints every tensor): db = sum over samples of dZ cancels to a few per cent of its terms there, so the fp16 rounding of dZ -- 5e-4
-of each term, what the weight tensors of the same cases show -- is 2e-3 ... 3e-2 of the sum.  Unchanged since round 2; batches of
-training size average it out (tests/test_gpu_edges.py::test_training_batch_properties)."""
+sample counts (ragged: not multiples of 32), widths, depths, weight scales and both forward arithmetics, through the product's
+default path (the backward is given the query points, so batches of <= 4096 samples take the fp32 backward of csrc/bwd_exact.hip
+and larger ones the fp16 kernels).  Run on the GPU box:  python tests/tools/fuzz_parity.py [n_cases] [seed].  Prints one line per
+case; exits 1 if any case is outside the gates (raw 2e-4 abs FAST / 5e-5 EXACT at O(1) outputs, image / weights 1e-4 of the tensor
+scale, EVERY gradient tensor 1e-3 rel L2 -- SURVEY 8d).  A fixed 24-case slice runs in the suite
+(tests/test_gpu_exact.py::test_fixed_slice_of_the_randomised_parity_sweep).
+FUZZ_FP16=1 withholds the query points, i.e. runs the fp16 backward kernels on every case as round 3 did: cases 23, 37 and 57
+(34 ... 1100 samples) then miss the gate (biases up to 2.7e-2, weights 1.2e-3) by exactly what single fp16 operands allow on sums that cancel -- every
+tensor is checked against conftest.fp16_chain_bounds instead (2^-12 sqrt(sources) kappa; tests/tools/bias_conditioning.py)."""
 import os
 import random
 import sys
@@ -13,59 +15,74 @@ import sys
 import torch
 
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(R, '2024-hl-spi3s-sunerf_amd')); sys.path.insert(0, os.path.join(R, 'oracle'))
+sys.path.insert(0, os.path.join(R, '2024-hl-spi3s-sunerf_amd')); sys.path.insert(0, os.path.join(R, 'oracle')); sys.path.insert(0, os.path.join(R, 'tests'))
 import sunerf_oracle as orc   # noqa: E402
 from sunerf_hip import ops    # noqa: E402
+from conftest import fp16_chain_bounds   # noqa: E402
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-bad = 0
-for case in range(n_cases):
-    d = rng.choice([64, 64, 128, 256, 256, 512])
-    L = rng.randint(1, 8) if d < 512 else rng.randint(1, 3)
-    n = rng.choice([1, 2, 3, 5, 17, 33, 64, 100, 255, 300])
-    S = rng.choice([2, 3, 31, 32, 33, 64, 65, 96, 127, 128, 130, 200])
-    scale = rng.choice([1.0, 1.0, 0.25, 2.0])
-    mode = rng.choice([ops.PRECISION_FAST, ops.PRECISION_EXACT])
-    train = d <= 256 or L <= 3
-    params = orc.init_params(d_filter=d, n_layers=L, seed=1000 + case)
-    params = [((W * scale) if 0 < i < len(params) - 1 else W, b) for i, (W, b) in enumerate(params)]
-    side = int(n ** 0.5) + 1
-    o, dd = orc.synthetic_rays(side)
-    o, dd = o[:n].contiguous(), dd[:n].contiguous()
-    g = torch.Generator().manual_seed(case)
-    t = torch.rand(n, 1, generator=g) * 3
-    z = orc.stratified_z(o, dd, orc.linspace_t_vals(S), torch.tensor(1.3), torch.tensor(1.0))
-    leaves = [(W.clone().requires_grad_(True), b.clone().requires_grad_(True)) for W, b in params]
-    ref = orc.render_pass(leaves, o, dd, t, z)
-    ref['raw'].retain_grad()
-    g_img = torch.randn(n, 1, generator=g)
-    (ref['image'] * g_img).sum().backward()
-    pk = ops.PackedMLP([W.cuda() for W, _ in params], [b.cuda() for _, b in params], precision=mode)
-    out = ops.emission_render_fwd(pk, o.cuda(), dd.cuda(), t.cuda(), z.cuda(), 1.2, want_raw=True, training=train)
-    e_raw = (out['raw'].cpu() - ref['raw'].detach()).abs().max().item() / max(1e-30, ref['raw'].detach().abs().max().item())
-    e_img = ((out['image'].cpu() - ref['image'].detach()).abs().max() / ref['image'].detach().abs().max()).item()
-    e_w = ((out['weights'].cpu() - ref['weights'].detach()).abs().max() / ref['weights'].detach().abs().max()).item()
-    e_g = 0.0
-    if train:
-        gW = [torch.empty_like(W).cuda() for W, _ in params]
-        gb = [torch.empty_like(b).cuda() for _, b in params]
-        ops.emission_render_bwd(pk, o.cuda(), dd.cuda(), z.cuda(), out['raw'], out['stash'], g_img.cuda(), None, 0.0, 1.2, gW, gb)
-        for li, ((W, b), w_, b_) in enumerate(zip(leaves, gW, gb)):
-            for nm, ref_g, got in (('W', W.grad, w_), ('b', b.grad, b_)):
-                if ref_g.norm() > 0:
-                    e = ((got.cpu() - ref_g).norm() / ref_g.norm()).item()
-                    e_g = max(e_g, e)
-                    if os.environ.get('FUZZ_VERBOSE') == str(case):
-                        print(f'      layer {li} {nm}: |ref| {ref_g.norm().item():.3e} rel err {e:.2e}  max|ref| {ref_g.abs().max().item():.2e}')
-        if os.environ.get('FUZZ_VERBOSE') == str(case):
-            gr = ref['raw'].grad.abs().reshape(-1)
-            print('      |g_raw| sorted top 6', [f'{v:.2e}' for v in gr.sort(descending=True)[0][:6].tolist()], 'median', f'{gr.median().item():.2e}', 'nonzero', int((gr > 0).sum()), 'of', gr.numel())
-            print('      |g_img|', g_img.abs().max().item(), 'image', ref['image'].detach().abs().max().item())
-    lim_raw = 2e-4 if mode == ops.PRECISION_FAST else 5e-5
-    ok = e_raw < lim_raw and e_img < 1e-4 and e_w < 1e-4 and e_g < 1.5e-3 and all(torch.isfinite(out[k]).all() for k in ('image', 'weights', 'raw'))
-    bad += not ok
-    print(f'{"ok " if ok else "BAD"} case {case:3d}: d={d:3d} L={L} rays={n:3d} S={S:3d} hidden x{scale:g} {ops.PRECISION_NAMES[mode]:5s} '
-          f'raw {e_raw:.1e} image {e_img:.1e} weights {e_w:.1e} grad {e_g:.1e}', flush=True)
-print(f'{n_cases - bad} of {n_cases} cases inside the gates')
-sys.exit(1 if bad else 0)
+
+
+def sweep(n_cases, seed=1, grad_gate=1e-3, verbose=print, fp16_only=False):
+    """Runs the first ``n_cases`` cases of the sequence ``seed`` defines; returns the list of (case, description) outside the gates."""
+    rng = random.Random(seed)
+    bad = []
+    for case in range(n_cases):
+        d = rng.choice([64, 64, 128, 256, 256, 512])
+        L = rng.randint(1, 8) if d < 512 else rng.randint(1, 3)
+        n = rng.choice([1, 2, 3, 5, 17, 33, 64, 100, 255, 300])
+        S = rng.choice([2, 3, 31, 32, 33, 64, 65, 96, 127, 128, 130, 200])
+        scale = rng.choice([1.0, 1.0, 0.25, 2.0])
+        mode = rng.choice([ops.PRECISION_FAST, ops.PRECISION_EXACT])
+        train = d <= 256 or L <= 3
+        params = orc.init_params(d_filter=d, n_layers=L, seed=1000 + case)
+        params = [((W * scale) if 0 < i < len(params) - 1 else W, b) for i, (W, b) in enumerate(params)]
+        side = int(n ** 0.5) + 1
+        o, dd = orc.synthetic_rays(side)
+        o, dd = o[:n].contiguous(), dd[:n].contiguous()
+        g = torch.Generator().manual_seed(case)
+        t = torch.rand(n, 1, generator=g) * 3
+        z = orc.stratified_z(o, dd, orc.linspace_t_vals(S), torch.tensor(1.3), torch.tensor(1.0))
+        leaves = [(W.clone().requires_grad_(True), b.clone().requires_grad_(True)) for W, b in params]
+        ref = orc.render_pass(leaves, o, dd, t, z)
+        ref['raw'].retain_grad()
+        g_img = torch.randn(n, 1, generator=g)
+        (ref['image'] * g_img).sum().backward()
+        pk = ops.PackedMLP([W.cuda() for W, _ in params], [b.cuda() for _, b in params], precision=mode)
+        out = ops.emission_render_fwd(pk, o.cuda(), dd.cuda(), t.cuda(), z.cuda(), 1.2, want_raw=True, training=train)
+        e_raw = (out['raw'].cpu() - ref['raw'].detach()).abs().max().item() / max(1e-30, ref['raw'].detach().abs().max().item())
+        e_img = ((out['image'].cpu() - ref['image'].detach()).abs().max() / ref['image'].detach().abs().max()).item()
+        e_w = ((out['weights'].cpu() - ref['weights'].detach()).abs().max() / ref['weights'].detach().abs().max()).item()
+        e_g, over = 0.0, 0.0
+        if train:
+            gW = [torch.empty_like(W).cuda() for W, _ in params]
+            gb = [torch.empty_like(b).cuda() for _, b in params]
+            ops.emission_render_bwd(pk, o.cuda(), dd.cuda(), z.cuda(), out['raw'], out['stash'], g_img.cuda(), None, 0.0, 1.2, gW, gb,
+                                    times=None if fp16_only else t.cuda())
+            bounds = fp16_chain_bounds(params, o, dd, t, z, ref['raw'].grad) if fp16_only else None
+            for li, ((W, b), w_, b_) in enumerate(zip(leaves, gW, gb)):
+                for nm, ref_g, got in (('W', W.grad, w_), ('b', b.grad, b_)):
+                    if ref_g.norm() > 0:
+                        e = ((got.cpu() - ref_g).norm() / ref_g.norm()).item()
+                        e_g = max(e_g, e)
+                        gate = bounds[nm == 'b'][li][1] if bounds is not None else grad_gate
+                        over = max(over, e / gate)
+                        if os.environ.get('FUZZ_VERBOSE') == str(case):
+                            verbose(f'      layer {li} {nm}: |ref| {ref_g.norm().item():.3e} rel err {e:.2e}  gate {gate:.1e}')
+        lim_raw = 2e-4 if mode == ops.PRECISION_FAST else 5e-5
+        ok = (e_raw < lim_raw and e_img < 1e-4 and e_w < 1e-4 and over <= 1.0
+              and all(torch.isfinite(out[k]).all() for k in ('image', 'weights', 'raw')))
+        line = (f'case {case:3d}: d={d:3d} L={L} rays={n:3d} S={S:3d} hidden x{scale:g} {ops.PRECISION_NAMES[mode]:5s} '
+                f'raw {e_raw:.1e} image {e_img:.1e} weights {e_w:.1e} grad {e_g:.1e} ({over:.2f} of its gate)')
+        if not ok:
+            bad.append((case, line))
+        verbose(('ok  ' if ok else 'BAD ') + line)
+    return bad
+
+
+if __name__ == '__main__':
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    fp16 = os.environ.get('FUZZ_FP16', '') not in ('', '0')
+    bad = sweep(n_cases, seed, fp16_only=fp16, verbose=lambda s: print(s, flush=True))
+    print(f'{n_cases - len(bad)} of {n_cases} cases inside the gates' + (' (fp16 backward kernels on every case, biases against their conditioning bound)' if fp16 else ''))
+    sys.exit(1 if bad else 0)
