@@ -62,7 +62,7 @@ struct PipeArgs {
   float* partial;           // [layer 0 .. n_act-1][pipeline][72 tiles][16][64]
   const float* g_raw;
   const unsigned* g_absmax_bits;
-  float* partial_out;       // prologue: [workgroup][9 tiles][16][64] (out layer)
+  float* partial_out;       // prologue: [workgroup][10 tiles][16][64]: dW_out (8), db_out, db of the last activation layer
   int64_t n_chunks_total;
   int S, n_chunks;          // samples per ray, chunks per ray
   int n_linear, d_out;
@@ -144,11 +144,29 @@ __device__ __forceinline__ void drain_matrix_pipe() { asm volatile("s_nop 15\n\t
   asm volatile("ds_read_b64_tr_b16 v[" #R0 ":" #R1 "], %1 offset:%2\n\tds_read_b64_tr_b16 v[" #R2 ":" #R3 "], %1 offset:%3" \
                : "={v[" #R0 ":" #R3 "]}"(var) : "v"(base), "i"(OFF), "i"((OFF) + 64) : "memory")
 
-__device__ __forceinline__ void dz_tile(const f32x16& acc, const half8& c0, const half8& c1, half8& d0, half8& d1) {
+// dZ = dH * cos of one 32 x 32 tile, rounded to (saturating) fp16 for the chain -- and, before that rounding, added to this
+// lane's running bias sums `bs` (db = sum over samples of dZ, in fp32: round 4; until then the weight-gradient waves summed
+// the ROUNDED dZ with v_dot2_f32_f16).  bs[g] = register g of the tile: row acc_row(g, h), this lane's sample column.
+__device__ __forceinline__ void dz_tile(const f32x16& acc, const half8& c0, const half8& c1, half8& d0, half8& d1, float* bs) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    d0[j] = (_Float16)sunerf_sat16(acc[j] * (float)c0[j]);
-    d1[j] = (_Float16)sunerf_sat16(acc[8 + j] * (float)c1[j]);
+    const float p0 = acc[j] * (float)c0[j], p1 = acc[8 + j] * (float)c1[j];
+    bs[j] += p0;
+    bs[8 + j] += p1;
+    d0[j] = (_Float16)sunerf_sat16(p0);
+    d1[j] = (_Float16)sunerf_sat16(p1);
+  }
+}
+// the 32 bias sums of a tile from the 16 x 64 per-lane sums: register g on lane half h is fragment-order index
+// 16 (g >> 3) + 8 h + (g & 7) of the tile (grad_common.h: reduce_grads_kernel reads bias slot `lane` as that index)
+__device__ __forceinline__ void store_bias_sums(const float* bs, float* dst32) {
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    float v = bs[g];
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 32);
+    if ((lane & 31) == 0) dst32[16 * (g >> 3) + 8 * h + (g & 7)] = v;
   }
 }
 
@@ -250,7 +268,11 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
 #if defined(PIPE_PRIO) && PIPE_PRIO == 1
     __builtin_amdgcn_s_setprio(1);
 #endif
-    constexpr int NO = 2, NP_D = 4;                  // output stores / DMA pieces (dZ fragments w, 4 + w, 8 + w, 12 + w) per iteration
+#ifndef PIPE_COS_ON_DATA
+#define PIPE_COS_ON_DATA 0      // experiment (round 4): the cos fragments of a data wave's own tile are fetched by that wave
+#endif
+    // output stores / DMA pieces (dZ fragments w, 4 + w, 8 + w, 12 + w [+ cos fragments 2 w, 2 w + 1]) per iteration
+    constexpr int NO = 2, NP_D = PIPE_COS_ON_DATA ? 6 : 4;
 #ifndef PIPE_PF
 #define PIPE_PF 4
 #endif
@@ -280,6 +302,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       const unsigned ab = lds_ld(lds_abort + (it & 1) * 4);
       next_chunk(it + NBUF - 1);
       piece_z(wave); piece_z(4 + wave); piece_z(8 + wave); piece_z(12 + wave);
+      if (PIPE_COS_ON_DATA) { piece_c(2 * wave); piece_c(2 * wave + 1); }
       const Rsrc sc = make_rsrc(scratch, 2048);
       const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
       buf_store(zero, sc, 0);
@@ -291,6 +314,9 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     const bool stamp = a.dbg != nullptr;
     char* out_z = ring_out;                        // ring slot of this iteration's output
     int out_slot = 0;
+    float bs[16];                                  // this lane's share of db_{l-1}[32 U ..]: fp32 sums of dH * cos
+#pragma unroll
+    for (int g = 0; g < 16; ++g) bs[g] = 0.f;
     for (int it = 0; it < (stop ? 0 : n_my); ++it) {
       const int buf = it & (NBUF - 1);
       unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
@@ -321,6 +347,8 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
         if (ks == 4) piece_z(4 + wave);
         if (ks == 7) piece_z(8 + wave);
         if (ks == 10) piece_z(12 + wave);
+        if (PIPE_COS_ON_DATA && ks == 12) piece_c(2 * wave);
+        if (PIPE_COS_ON_DATA && ks == 14) piece_c(2 * wave + 1);
         if (ks == PKS - PF) {            // the last B fragment has been requested: cos of this wave's tile
           c0f = *(const half8*)(B + (24 + 2 * wave) * 1024 + lane * 16);
           c1f = *(const half8*)(B + (25 + 2 * wave) * 1024 + lane * 16);
@@ -330,7 +358,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       if (stamp) { asm volatile("" :: "v"(dacc)); s3 = __builtin_amdgcn_s_memtime(); }
       // dZ_{l-1} = dH * cos (fp16, saturating) -> ring slot, fragments 2 U, 2 U + 1 of the chunk
       half8 d0, d1;
-      dz_tile(dacc, c0f, c1f, d0, d1);
+      dz_tile(dacc, c0f, c1f, d0, d1, bs);
       const Rsrc ro = make_rsrc(out_z, SLOT);
       buf_store(d0, ro, (2 * U) * 1024);
       buf_store(d1, ro, (2 * U + 1) * 1024);
@@ -345,6 +373,9 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     barrier_mem();
+    // db_{l-1}, row tile U, of this pipeline: the bias column of layer l-1's partial-sum slot (every slot is written exactly once:
+    // a workgroup without chunks writes its zeros)
+    store_bias_sums(bs, a.partial + ((size_t)(l - 1) * a.NP + P) * (PT * (PT + 1)) * 1024 + ((size_t)U * (PT + 1) + PT) * 1024);
     if (stamp && P == 0 && lane == 0) {      // timeline of iteration n_my / 2: [workgroup of the pipeline][wave][8] 64-bit shader clocks
       unsigned long long* t = (unsigned long long*)(a.dbg + 256 * 8 * 4) + (((size_t)(blockIdx.x >> 3) * 8 + wave) * 8);
       for (int k = 0; k < 5; ++k) t[k] = tl[k];
@@ -362,13 +393,11 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
 #endif
   const int v = wave - 4;
   const bool gatew = v == 0;
-  // block of this wave: row tiles 4 rq .. +3 (features of dZ_l), column tiles 2 cq, 2 cq + 1 of J_j; db_l (workgroup 0 of the
-  // pair): every wave sums two of its four row tiles
+  // block of this wave: row tiles 4 rq .. +3 (features of dZ_l), column tiles 2 cq, 2 cq + 1 of J_j (db_l is summed where dZ_l is
+  // formed: by the data-gradient waves of the stage above, or by the prologue)
   const int rq = v >> 1, cq = v & 1;
   const int r0 = 4 * rq, c0 = 2 * cq;
-  const bool do_bias = j == 0;
   f32x16 acc[4][2];
-  float bsum[2] = {0.f, 0.f};
   {
     // zero tiles DEFINED in AGPRs (0 * 0 + 0 by the matrix pipe): a `= {0}` gives the loop-carried tiles a VGPR home and hipcc
     // then copies 16 registers into AGPRs in front of every matrix instruction and back behind it
@@ -427,6 +456,12 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   const bool stamp = a.dbg != nullptr;
   auto weight_pieces = [&]() __attribute__((always_inline)) {
     if (gatew) { piece_h(0); return; }
+#if PIPE_COS_ON_DATA
+    // H 1 .. 7 over waves 5, 6, 7: 2, 2, 3 pieces (the cos fragments come in through the data waves)
+    piece_h(2 * v - 1); piece_h(2 * v);
+    if (v == 3) piece_h(7);
+    return;
+#endif
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
       const int g = 5 * (v - 1) + q;                       // 0 .. 14 over [H 1 .. 7, cos 0 .. 7]
@@ -440,7 +475,12 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     unsigned long long sa = 0, sb = 0;
     if (stamp) sa = __builtin_amdgcn_s_memtime();
     if (gatew) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * (1 + 2)) : "memory");
+#if PIPE_COS_ON_DATA
+    else if (v == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * 3) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * 2) : "memory");
+#else
     else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * 5) : "memory");
+#endif
     if (stamp) sb = __builtin_amdgcn_s_memtime();
     barrier_mem();
     if (stamp) { t_wait = sb; t_bar = __builtin_amdgcn_s_memtime(); tw += sb - sa; tb += t_bar - sb; }
@@ -515,14 +555,6 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
         const half8 af = ks ? A1[i] : A0[i];
         mfma_agpr(acc[i][0], af, bf0);
         mfma_agpr(acc[i][1], af, bf1);
-        if (do_bias && (i >> 1) == cq) {
-          const half2v one2 = {(_Float16)1, (_Float16)1};
-#pragma unroll
-          for (int e = 0; e < 8; e += 2) {
-            const half2v pr = {af[e], af[e + 1]};
-            bsum[i & 1] = __builtin_amdgcn_fdot2(pr, one2, bsum[i & 1], false);
-          }
-        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -560,13 +592,6 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     for (int jj = 0; jj < 2; ++jj) {
       store_tile(acc[i][jj], out + ((size_t)(r0 + i) * (PT + 1) + (4 * j + c0 + jj)) * 1024);
     }
-  if (do_bias) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float bv = bsum[i] + __shfl_xor(bsum[i], 32);
-      if (lane < 32) out[((size_t)(r0 + 2 * cq + i) * (PT + 1) + PT) * 1024 + lane] = bv;
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -593,7 +618,6 @@ __device__ __forceinline__ void in_stage(const PipeArgs& a, char* smem, int P, i
   unsigned* status = a.ctrl;
 
   f32x16 acc[3];
-  float bsum = 0.f;
 #pragma unroll
   for (int c = 0; c < 3; ++c) acc[c] = (f32x16){0};
 
@@ -668,12 +692,6 @@ __device__ __forceinline__ void in_stage(const PipeArgs& a, char* smem, int P, i
       const half8 af = join(alo, ahi);
 #pragma unroll
       for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, join(blo[c], bhi[c]), acc[c], 0, 0, 0);
-      const half2v one2 = {(_Float16)1, (_Float16)1};
-#pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        const half2v pr = {af[e], af[e + 1]};
-        bsum = __builtin_amdgcn_fdot2(pr, one2, bsum, false);
-      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -691,8 +709,7 @@ __device__ __forceinline__ void in_stage(const PipeArgs& a, char* smem, int P, i
   for (int c = 0; c < 3; ++c) {
     store_tile(acc[c], out + ((size_t)tr * (PT + 1) + c) * 1024);
   }
-  const float v = bsum + __shfl_xor(bsum, 32);
-  if (lane < 32) out[((size_t)tr * (PT + 1) + PT) * 1024 + lane] = v;
+  // (db_0 is summed by the data-gradient waves of stage 1, which form dZ_0)
 }
 
 template <bool HI_ONLY>
@@ -777,7 +794,10 @@ __global__ __launch_bounds__(WG_PRE, 1) void bwd_prologue_kernel(PipeArgs a) {
   for (int t = 0; t < 2; ++t) aT[t] = *(const half8*)(a.packedT + (size_t)(2 * wave + t) * 1024 + lane * 16);
 
   f32x16 acc[2] = {(f32x16){0}, (f32x16){0}};
-  float bsum = 0.f;
+  float bs[2][16];          // fp32 bias sums of the last activation layer, tiles 2 w and 2 w + 1 (this lane's samples)
+#pragma unroll
+  for (int g = 0; g < 16; ++g) { bs[0][g] = 0.f; bs[1][g] = 0.f; }
+  float gsum0 = 0.f, gsum1 = 0.f;       // wave 0: db of the out layer = sum of the (scaled) fp32 g_raw itself
   const size_t act_chunk = SL.chunk_bytes();
   const char* srcH0 = a.act_stash + SL.h_off(n_act - 1) + lane * 16;
   const char* srcC0 = a.act_stash + SL.c_off(n_act - 1) + lane * 16;
@@ -820,8 +840,11 @@ __global__ __launch_bounds__(WG_PRE, 1) void bwd_prologue_kernel(PipeArgs a) {
       (void)ray;
       if (h == 0 && i < a.S) {
         const f32x2 g = *(const f32x2*)(smem + (size_t)buf * BUF_PRE + 34 * 1024 + n * 8);
-        dzo[0] = (_Float16)(g[0] * gscale);
-        if (a.d_out > 1) dzo[1] = (_Float16)(g[1] * gscale);
+        const float g0 = g[0] * gscale, g1 = a.d_out > 1 ? g[1] * gscale : 0.f;
+        dzo[0] = (_Float16)g0;
+        dzo[1] = (_Float16)g1;
+        gsum0 += g0;
+        gsum1 += g1;
       }
       if (wave == 0) *(half8*)(smem + (size_t)buf * BUF_PRE + 32 * 1024 + lane * 16) = dzo;
       else if (wave == 1) *(half8*)(smem + (size_t)buf * BUF_PRE + 33 * 1024 + lane * 16) = (half8){0, 0, 0, 0, 0, 0, 0, 0};
@@ -846,7 +869,7 @@ __global__ __launch_bounds__(WG_PRE, 1) void bwd_prologue_kernel(PipeArgs a) {
       const half8 c0f = *(const half8*)(B + (16 + 2 * U) * 1024 + lane * 16);
       const half8 c1f = *(const half8*)(B + (17 + 2 * U) * 1024 + lane * 16);
       half8 d0, d1;
-      dz_tile(d, c0f, c1f, d0, d1);
+      dz_tile(d, c0f, c1f, d0, d1, bs[t]);
       buf_store(d0, ro, (2 * U) * 1024);
       buf_store(d1, ro, (2 * U + 1) * 1024);
     }
@@ -865,25 +888,22 @@ __global__ __launch_bounds__(WG_PRE, 1) void bwd_prologue_kernel(PipeArgs a) {
       const half8 af = join(alo, ahi);
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, join(blo[t], bhi[t]), acc[t], 0, 0, 0);
-      if (wave == 0) {
-        const half2v one2 = {(_Float16)1, (_Float16)1};
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-          const half2v pr = {af[e], af[e + 1]};
-          bsum = __builtin_amdgcn_fdot2(pr, one2, bsum, false);
-        }
-      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  float* out = a.partial_out + (size_t)blockIdx.x * (PT + 1) * 1024;
+  // per workgroup: [8 tiles dW_out][tile PT: db_out, 32 floats][tile PT + 1: db of the last activation layer, 8 row tiles x 32]
+  float* out = a.partial_out + (size_t)blockIdx.x * (PT + 2) * 1024;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     store_tile(acc[t], out + (size_t)(2 * wave + t) * 1024);
+    store_bias_sums(bs[t], out + (size_t)(PT + 1) * 1024 + (2 * wave + t) * 32);
   }
   if (wave == 0) {
-    const float v = bsum + __shfl_xor(bsum, 32);
-    if (lane < 32) out[(size_t)PT * 1024 + lane] = v;
+    // g_raw sits on the lanes of half 0 (one sample each); bias slot lane i = output index i (fragment-order index i: s = 0,
+    // h = 0, e = i for i < 8)
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) { gsum0 += __shfl_xor(gsum0, d, 32); gsum1 += __shfl_xor(gsum1, d, 32); }
+    if (lane < 32) out[(size_t)PT * 1024 + lane] = lane == 0 ? gsum0 : (lane == 1 ? gsum1 : 0.f);
   }
 }
 
@@ -907,7 +927,7 @@ struct PipeLayout {
     rings = off; off += up((size_t)NP * n_links * RING * SLOT + (size_t)cus * 4 * 2048);
     dz_top = off; off += up((size_t)(n_chunks_total > 0 ? n_chunks_total : 1) * SLOT);
     partial = off; off += up((size_t)n_act * NP * PT * (PT + 1) * 1024 * sizeof(float));
-    partial_out = off; off += up((size_t)cus * (PT + 1) * 1024 * sizeof(float));
+    partial_out = off; off += up((size_t)cus * (PT + 2) * 1024 * sizeof(float));
     total = off;
   }
 };
@@ -1000,7 +1020,18 @@ extern "C" int sunerf_mlp_backward_pipe(int d_filter, int n_linear, int d_out, c
     } else {
       r.partial[i] = a.partial_out;
       r.split[i] = cus;
-      r.slot[i] = (size_t)(PT + 1) * 1024;
+      r.slot[i] = (size_t)(PT + 2) * 1024;
+    }
+    if (i < n_linear - 2) {                 // db_i: summed by the data-gradient waves of stage i + 1 into layer i's own slots
+      r.bias[i] = r.partial[i] + (size_t)PT * 1024;
+      r.bias_split[i] = L.NP;
+      r.bias_slot[i] = slot;
+      r.bias_tr[i] = (size_t)(PT + 1) * 1024;
+    } else {                                // last activation layer and out layer: summed by the prologue's workgroups
+      r.bias[i] = a.partial_out + (size_t)(i == n_linear - 1 ? PT : PT + 1) * 1024;
+      r.bias_split[i] = cus;
+      r.bias_slot[i] = (size_t)(PT + 2) * 1024;
+      r.bias_tr[i] = 32;
     }
   }
   r.g_absmax_bits = (const unsigned*)g_absmax; r.n_linear = n_linear; r.D = d_filter; r.d_out = d_out; r.accumulate = accumulate;

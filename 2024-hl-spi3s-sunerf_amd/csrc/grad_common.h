@@ -48,6 +48,14 @@ struct ReduceArgs {
   const float* partial[SUNERF_MAX_LAYERS];
   int split[SUNERF_MAX_LAYERS];
   size_t slot[SUNERF_MAX_LAYERS];
+  // bias sums of layer l: 32 floats per row tile at bias[l] + tr * bias_tr[l], in `bias_split[l]` slots `bias_slot[l]` floats apart.
+  // (The two-kernel backward keeps them in the bias column of the partial-sum slots: bias = partial + T * 1024, bias_tr =
+  // (T + 1) * 1024; the pipelined backward sums db_l in fp32 where dZ_l is FORMED -- the stage above, or the prologue -- so some
+  // layers' sums live in another workgroup's slots.)
+  const float* bias[SUNERF_MAX_LAYERS];
+  int bias_split[SUNERF_MAX_LAYERS];
+  size_t bias_slot[SUNERF_MAX_LAYERS];
+  size_t bias_tr[SUNERF_MAX_LAYERS];
   const unsigned* g_absmax_bits;
   float* gW[SUNERF_MAX_LAYERS];
   float* gb[SUNERF_MAX_LAYERS];
@@ -93,10 +101,12 @@ __global__ void reduce_grads_kernel(ReduceArgs a) {
   const int fa = 32 * tr + fa_row;                      // fragment-order index on the dZ side
   const int j = (layer == a.n_linear - 1) ? fa : frag_feature_hidden(fa);   // out layer: feature index = output index
   if (j >= rows) return;
-  const size_t slot = a.slot[layer];
-  const float* p = a.partial[layer] + ((size_t)tr * (T + 1) + tc) * 1024 + reg * 64 + lane;
+  const bool is_bias = tc == T;
+  const size_t slot = is_bias ? a.bias_slot[layer] : a.slot[layer];
+  const float* p = is_bias ? a.bias[layer] + (size_t)tr * a.bias_tr[layer] + lane
+                           : a.partial[layer] + ((size_t)tr * (T + 1) + tc) * 1024 + reg * 64 + lane;
   // (four independent loads in flight: one dependent load per partial made this kernel latency-bound at 80 us)
-  const int ns = a.split[layer];
+  const int ns = is_bias ? a.bias_split[layer] : a.split[layer];
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int s = 0;
   for (; s + 4 <= ns; s += 4) {

@@ -295,8 +295,13 @@ extern "C" int sunerf_mlp_wgrad(int d_filter, int n_linear, int d_out, const voi
     r.partial[i] = (const float*)workspace + (size_t)i * split * slot;
     r.split[i] = split;
     r.slot[i] = slot;
+    r.bias[i] = r.partial[i] + (size_t)wg_tiles(d_filter) * 1024;          // the bias column of the same slots
+    r.bias_split[i] = split;
+    r.bias_slot[i] = slot;
+    r.bias_tr[i] = (size_t)(wg_tiles(d_filter) + 1) * 1024;
   }
   r.status = nullptr;
+  r.sticky = nullptr;
   r.g_absmax_bits = (const unsigned*)g_absmax; r.n_linear = n_linear; r.D = d_filter;
   // the boosts sunerf_pack_mlp_t folded into the transposed image the data gradient went through (its tail holds their source)
   r.sumsq = (const float*)((const char*)packedT + sunerf_packed_mlp_t_bytes(d_filter, n_linear) - SUNERF_MAX_LAYERS * sizeof(float));

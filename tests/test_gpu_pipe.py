@@ -86,8 +86,10 @@ def test_pipelined_backward_matches_oracle_and_two_kernel_backward(ops, n_side, 
             e_cls = ((p - c).norm() / c.norm()).item()
             worst_ref, worst_classic = max(worst_ref, e_ref), max(worst_classic, e_cls)
             assert e_ref < 1e-3, (i, name, 'vs oracle', e_ref)
-            # same operands, same products (fp16 heads + remainders of W^T, fp16 H / cos / dZ): only the order of the fp32 sums differs
-            assert e_cls < 2e-5, (i, name, 'vs two-kernel backward', e_cls)
+            # weights: same operands, same products (fp16 heads + remainders of W^T, fp16 H / cos / dZ), only the order of the fp32
+            # sums differs.  Biases: the pipelined backward sums dH * cos in fp32 BEFORE its rounding to fp16 (round 4), the two-kernel
+            # one sums the rounded dZ: they differ by that rounding's share, 2^-12 / sqrt(samples) x the sum's conditioning
+            assert e_cls < (2e-5 if name == 'weight' else 3e-4), (i, name, 'vs two-kernel backward', e_cls)
     print(f'{o.shape[0]} rays x {S}, {n_layers} layers: pipelined vs oracle {worst_ref:.2e}, vs two-kernel {worst_classic:.2e}')
 
 
@@ -140,7 +142,7 @@ def test_training_batch_through_pipelined_backward(ops):
     pipe, status = _hip_grads(ops, 'pipe', params, o, d, t, z, g_image, 2e-5)
     assert status == 0
     for (cW, cb), (pW, pb) in zip(classic, pipe):
-        assert ((pW - cW).norm() / cW.norm()).item() < 5e-5 and ((pb - cb).norm() / cb.norm()).item() < 5e-5
+        assert ((pW - cW).norm() / cW.norm()).item() < 5e-5 and ((pb - cb).norm() / cb.norm()).item() < 3e-4   # (biases: fp32 sums here)
 
 
 def test_a_launch_that_gives_up_leaves_nan_gradients_and_the_process_falls_back(ops, monkeypatch):
