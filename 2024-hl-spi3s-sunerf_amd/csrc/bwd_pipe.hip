@@ -42,12 +42,14 @@ namespace {
 constexpr int PD = 256, PKS = PD / 16, PNT = PD / 32, PT = 8;   // d_filter, fragments / tiles per layer, workspace tiles
 constexpr int WG = 512;                 // pipelined kernel: eight waves, two per SIMD
 constexpr int WG_PRE = 256;             // prologue kernel
-constexpr int NBUF = 4;                 // staging buffers per workgroup (chunks in flight: NBUF - 1)
+constexpr int NBUF = 4;                 // staging buffers of the in-layer stage and of the prologue (chunks in flight: NBUF - 1)
+constexpr int NBUF_H = 5;               // ... of a hidden stage: chunk it + 4 is being fetched, chunk it + 1's phases are decoded, chunk it is consumed
+constexpr int DRAIN = 4;                // a wave's output stores of chunk c have left it by its counted wait of iteration c + DRAIN
 constexpr int RING = 16;                // chunk slots per hand-off ring
 constexpr int SLOT = PKS * 1024;        // one chunk of dZ: 16 fragments
-constexpr int BUF_HID = 32 * 1024;      // hidden stage staging: dZ_l 16 | H[J] 8 | cos[J] 8 KiB
+constexpr int BUF_HID = 24 * 1024;      // hidden stage staging: dZ_l 16 | P[J] 8 KiB (16-bit phases, decoded IN PLACE to fp16 sin = H[J])
 constexpr int BUF_IN = 16 * 1024;       // in-layer stage staging: dZ_0[J] 8 | enc 6 (| 2 unused) KiB
-constexpr int BUF_PRE = 35 * 1024;      // prologue staging: H 16 | cos 16 | dZ_out operand tile 2 KiB | g_raw of the chunk 256 B
+constexpr int BUF_PRE = 19 * 1024;      // prologue staging: P 16 (decoded in place to H) | dZ_out operand tile 2 KiB | g_raw of the chunk 256 B
 constexpr unsigned SPIN_LIMIT = 50000000u;   // s_memrealtime ticks (100 MHz): 0.5 s
 
 // status codes (word 0 of the control block)
@@ -147,10 +149,10 @@ __device__ __forceinline__ void drain_matrix_pipe() { asm volatile("s_nop 15\n\t
 // dZ = dH * cos of one 32 x 32 tile, rounded to (saturating) fp16 for the chain -- and, before that rounding, added to this
 // lane's running bias sums `bs` (db = sum over samples of dZ, in fp32: round 4; until then the weight-gradient waves summed
 // the ROUNDED dZ with v_dot2_f32_f16).  bs[g] = register g of the tile: row acc_row(g, h), this lane's sample column.
-__device__ __forceinline__ void dz_tile(const f32x16& acc, const half8& c0, const half8& c1, half8& d0, half8& d1, float* bs) {
+__device__ __forceinline__ void dz_tile(const f32x16& acc, const float* c0, const float* c1, half8& d0, half8& d1, float* bs) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float p0 = acc[j] * (float)c0[j], p1 = acc[8 + j] * (float)c1[j];
+    const float p0 = acc[j] * c0[j], p1 = acc[8 + j] * c1[j];
     bs[j] += p0;
     bs[8 + j] += p1;
     d0[j] = (_Float16)sunerf_sat16(p0);
@@ -168,6 +170,23 @@ __device__ __forceinline__ void store_bias_sums(const float* bs, float* dst32) {
     for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 32);
     if ((lane & 31) == 0) dst32[16 * (g >> 3) + 8 * h + (g & 7)] = v;
   }
+}
+
+// 8 phases (one lane's 16 bytes of a phase fragment, sunerf_common.h: SUNERF_STASH_PHASE) -> sin and cos of the pre-activations
+__device__ __forceinline__ void decode_phases(const v4u& p, float* sn, float* cs) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const unsigned w = p[e >> 1];
+    const float rev = (float)((e & 1) ? (w >> 16) : (w & 0xffffu)) * SUNERF_PHASE_SCALE;
+    sn[e] = __builtin_amdgcn_sinf(rev);
+    cs[e] = __builtin_amdgcn_cosf(rev);
+  }
+}
+__device__ __forceinline__ half8 to_half8(const float* v) {
+  half8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (_Float16)v[e];
+  return r;
 }
 
 // 4-byte LDS words by LDS address: a `volatile` access through a generic pointer becomes a FLAT load, which hipcc follows
@@ -206,73 +225,80 @@ template <bool HI_ONLY, bool TOP>
 __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int P, int l, int j, int64_t cbeg, int n_my) {
   // EIGHT waves, two per SIMD, with different jobs (one register budget of 256 per wave, two simple loops instead of one that
   // needs 400 registers -- hipcc rotated whole accumulator tiles between the register-file halves in that one):
-  //   waves 0..3 ("data"):   dH tile 4 j + w = W_l^T dZ_l (W^T fragments resident in AGPRs), dZ_{l-1} = dH * cos -> ring
-  //   waves 4..7 ("weight"): the 4 x 2 accumulator tiles of dW_l[:, J_j] (+ db_l), the hand-off protocol (wave 4)
+  //   waves 0..3 ("data"):   dH tile 4 j + w = W_l^T dZ_l (W^T fragments resident in AGPRs), dZ_{l-1} = dH * cos -> ring, db_{l-1};
+  //                          ALL of the workgroup's DMA; the decoding of the phase stash (below)
+  //   waves 4..7 ("weight"): the 4 x 2 accumulator tiles of dW_l[:, J_j]; the hand-off protocol (wave 4)
   // The two waves of a SIMD share its matrix pipe; while one issues LDS reads, DMA pieces or the epilogue, the other's
   // matrix instructions run.
+  //
+  // PHASE STASH [r4].  The forward leaves ONE 16-bit phase per pre-activation (sunerf_common.h) instead of an fp16 sin and an fp16
+  // cos: per chunk this workgroup takes in dZ_l (16 KiB) and the phases of ITS 128 features of layer l-1 (8 KiB, was 16).  Data wave
+  // w fetches the two phase fragments of its own output tile itself, and one iteration before the chunk is consumed it decodes
+  // them: sin -> fp16, written back IN PLACE (the LDS image the weight-gradient waves read with ds_read_b64_tr_b16 is the same as
+  // before), cos -> 16 registers for its own epilogue of the next iteration.  That work (2 LDS reads, 48 vector instructions
+  // 16 of them transcendental, 2 LDS writes) sits where these waves used to wait at the barrier; the weight-gradient waves -- the
+  // workgroup's critical path once W^T is a single fp16 image -- issue no DMA at all any more.
+  // Per iteration `it`: chunk it + NBUF_H - 1 is requested, chunk it + 1's phases (requested three iterations ago by this very
+  // wave: its own counted wait covers them) are decoded, chunk it is consumed.
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n_act = a.n_linear - 1, n_links = n_act - 1;
-  const StashLayout SL(PD, a.n_linear);
+  const StashLayout SL(PD, a.n_linear, true);
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
-  const unsigned lds_dummy = lds0 + NBUF * BUF_HID;
+  const unsigned lds_dummy = lds0 + NBUF_H * BUF_HID;
   const unsigned lds_poll = lds_dummy + 1024;
-  const unsigned lds_abort = lds_poll + NBUF * 256;      // [2]
+  const unsigned lds_abort = lds_poll + NBUF_H * 256;      // [2]
   unsigned* status = a.ctrl;
   const unsigned voff = lane * 16;
 
   char* ring_in = TOP ? nullptr : a.rings + ((size_t)P * n_links + l) * RING * SLOT;
   char* ring_out = a.rings + ((size_t)P * n_links + (l - 1)) * RING * SLOT;
   const size_t act_chunk = SL.chunk_bytes();
-  const char* srcH0 = a.act_stash + SL.h_off(l - 1) + (size_t)(8 * j) * 1024;
-  const char* srcC0 = a.act_stash + SL.c_off(l - 1) + (size_t)(8 * j) * 1024;
+  const char* srcP0 = a.act_stash + SL.h_off(l - 1) + (size_t)(8 * j) * 1024;
   const int64_t safe = cbeg < a.n_chunks_total ? cbeg : a.n_chunks_total - 1;     // a chunk inside the stashes for surplus DMA
 
-  // wave-uniform sources / LDS destination of the chunk being fetched (nxt = it + NBUF - 1), set at the top of an iteration
-  const char *nz = nullptr, *nh = nullptr, *nc = nullptr;
+  // wave-uniform sources / LDS destination of the chunk being fetched (nxt = it + NBUF_H - 1), set at the top of an iteration
+  const char *nz = nullptr, *np = nullptr;
   unsigned ndst = 0;
   bool nreal = false;
   // (called with nxt = 0, 1, 2, ... in turn: the addresses advance by additions -- 64-bit multiplications here cost every wave
   // several hundred cycles per chunk)
-  const char* const safe_h = srcH0 + (size_t)safe * act_chunk;
-  const char* const safe_c = srcC0 + (size_t)safe * act_chunk;
+  const char* const safe_p = srcP0 + (size_t)safe * act_chunk;
   const char* const safe_z = TOP ? a.dz_top + (size_t)safe * SLOT : ring_in;
-  const char *run_h = srcH0 + (size_t)cbeg * act_chunk, *run_c = srcC0 + (size_t)cbeg * act_chunk;
+  const char* run_p = srcP0 + (size_t)cbeg * act_chunk;
   const char* run_z = TOP ? a.dz_top + (size_t)cbeg * SLOT : ring_in;
-  int run_slot = 0;
+  int run_slot = 0, run_buf = 0;
   auto next_chunk = [&](int nxt) __attribute__((always_inline)) {
     nreal = nxt < n_my;
-    ndst = lds0 + (nxt & (NBUF - 1)) * BUF_HID;
+    ndst = lds0 + run_buf * BUF_HID;
+    run_buf = run_buf + 1 == NBUF_H ? 0 : run_buf + 1;
     nz = nreal ? run_z : safe_z;
-    nh = nreal ? run_h : safe_h;
-    nc = nreal ? run_c : safe_c;
-    run_h += act_chunk;
-    run_c += act_chunk;
+    np = nreal ? run_p : safe_p;
+    run_p += act_chunk;
     if (TOP) run_z += SLOT;
     else {
       run_slot = run_slot + 1 == RING ? 0 : run_slot + 1;
       run_z = run_slot == 0 ? ring_in : run_z + SLOT;
     }
   };
-  // LDS image of a chunk: pieces 0..15 dZ fragments, 16..23 H[J], 24..31 cos[J]
+  // LDS image of a chunk: pieces 0..15 dZ fragments, 16..23 P[J] (decoded in place to H[J])
   auto piece_z = [&](int f) __attribute__((always_inline)) {
     const unsigned dst = nreal ? ndst + f * 1024 : lds_dummy;
     if (TOP) dma_piece_s<1>(nz + (size_t)f * 1024, voff, dst);
     else dma_piece_s<2>(nz + (size_t)f * 1024, voff, dst);
   };
-  auto piece_h = [&](int f) __attribute__((always_inline)) { dma_piece_s<1>(nh + (size_t)f * 1024, voff, nreal ? ndst + (16 + f) * 1024 : lds_dummy); };
-  auto piece_c = [&](int f) __attribute__((always_inline)) { dma_piece_s<1>(nc + (size_t)f * 1024, voff, nreal ? ndst + (24 + f) * 1024 : lds_dummy); };
+  auto piece_p = [&](int f) __attribute__((always_inline)) { dma_piece_s<1>(np + (size_t)f * 1024, voff, nreal ? ndst + (16 + f) * 1024 : lds_dummy); };
 
   if (wave < 4) {
     // =============================================== data-gradient waves ===============================================
 #if defined(PIPE_PRIO) && PIPE_PRIO == 1
     __builtin_amdgcn_s_setprio(1);
 #endif
-#ifndef PIPE_COS_ON_DATA
-#define PIPE_COS_ON_DATA 0      // experiment (round 4): the cos fragments of a data wave's own tile are fetched by that wave
+#ifndef PIPE_PHASE_ON_WEIGHT
+#define PIPE_PHASE_ON_WEIGHT 0      // experiment: the phase pieces are fetched by the weight-gradient waves (two each, between their matrix instructions)
 #endif
-    // output stores / DMA pieces (dZ fragments w, 4 + w, 8 + w, 12 + w [+ cos fragments 2 w, 2 w + 1]) per iteration
-    constexpr int NO = 2, NP_D = PIPE_COS_ON_DATA ? 6 : 4;
+    // output stores / DMA pieces (dZ fragments w, 4 + w, 8 + w, 12 + w; phase fragments 2 w, 2 w + 1 of this wave's own tile) per iteration
+    constexpr int NO = 2, NP_D = PIPE_PHASE_ON_WEIGHT ? 4 : 6;
 #ifndef PIPE_PF
 #define PIPE_PF 4
 #endif
@@ -294,48 +320,78 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       }
     }
     char* scratch = a.rings + (size_t)a.NP * n_links * RING * SLOT + ((size_t)blockIdx.x * 4 + wave) * 2048;
-    // prologue iterations -(NBUF-1) .. -1: DMA only (+ two dummy stores: the same vmcnt accounting as a full iteration)
+    // cos of this wave's tile for the chunk consumed NEXT (decoded one iteration ahead), and the decoder: the two phase fragments
+    // of the tile (this wave's OWN DMA pieces: its counted wait covers them) -> fp16 sin in place (the H image of the
+    // weight-gradient waves, who see it behind the next barrier) + cos here.  It runs behind the epilogue, where these waves used
+    // to wait ~900 clocks at the barrier once W^T is a single fp16 image; the LDS reads are issued a few k-steps earlier.
+    // Measured alternatives (tools/experiments/README.md, round 4; this one: kernel 12.0 ms): decoding dealt out over the k-steps
+    // 12.2 (k-steps 1050 -> 2120 clocks), the sin half on the weight-gradient waves 12.9 (900 clocks there for half the work), all
+    // DMA on the weight-gradient waves 13.5 (seven pieces in a row cost them 250 clocks each).
+    float cosn[16];
+    typedef __attribute__((address_space(3))) v4u lds_v4u;
+    typedef __attribute__((address_space(3))) half8 lds_half8;
+    v4u dp[2];
+    auto read_phases = [&](int b) __attribute__((always_inline)) {
+      const unsigned at = lds0 + b * BUF_HID + (16 + 2 * wave) * 1024 + voff;
+      dp[0] = *(const lds_v4u*)(uintptr_t)at;
+      dp[1] = *(const lds_v4u*)(uintptr_t)(at + 1024);
+    };
+    auto decode = [&](int b) __attribute__((always_inline)) {
+      const unsigned at = lds0 + b * BUF_HID + (16 + 2 * wave) * 1024 + voff;
+      float sn[16];
+      decode_phases(dp[0], sn, cosn);
+      decode_phases(dp[1], sn + 8, cosn + 8);
+      *(lds_half8*)(uintptr_t)at = to_half8(sn);
+      *(lds_half8*)(uintptr_t)(at + 1024) = to_half8(sn + 8);
+    };
+    // prologue iterations -(NBUF_H-1) .. -1: DMA only (+ two dummy stores: the same vmcnt accounting as a full iteration); the
+    // last of them decodes chunk 0
     bool stop = false;
-    for (int it = -(NBUF - 1); it < 0; ++it) {
+    for (int it = -(NBUF_H - 1); it < 0; ++it) {
       asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NO + 2 * (NP_D + NO)) : "memory");
       barrier_mem();
       const unsigned ab = lds_ld(lds_abort + (it & 1) * 4);
-      next_chunk(it + NBUF - 1);
+      next_chunk(it + NBUF_H - 1);
       piece_z(wave); piece_z(4 + wave); piece_z(8 + wave); piece_z(12 + wave);
-      if (PIPE_COS_ON_DATA) { piece_c(2 * wave); piece_c(2 * wave + 1); }
+      if (!PIPE_PHASE_ON_WEIGHT) { piece_p(2 * wave); piece_p(2 * wave + 1); }
       const Rsrc sc = make_rsrc(scratch, 2048);
       const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
       buf_store(zero, sc, 0);
       buf_store(zero, sc, 1024);
       if (ab) { stop = true; break; }
+      if (it == -1 && n_my > 0) { read_phases(0); decode(0); }
     }
-    unsigned long long ph[4] = {0, 0, 0, 0};      // SUNERF_PIPE_DEBUG: shader clocks in wait / barrier / k-steps / epilogue
+    unsigned long long ph[4] = {0, 0, 0, 0};      // SUNERF_PIPE_DEBUG: shader clocks in wait / barrier / k-steps / epilogue + decode
     unsigned long long tl[5] = {0, 0, 0, 0, 0};   //   and the stamps of iteration n_my / 2 themselves
     const bool stamp = a.dbg != nullptr;
     char* out_z = ring_out;                        // ring slot of this iteration's output
-    int out_slot = 0;
+    int out_slot = 0, buf = 0;                     // buf = it % NBUF_H
     float bs[16];                                  // this lane's share of db_{l-1}[32 U ..]: fp32 sums of dH * cos
 #pragma unroll
     for (int g = 0; g < 16; ++g) bs[g] = 0.f;
     for (int it = 0; it < (stop ? 0 : n_my); ++it) {
-      const int buf = it & (NBUF - 1);
       unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
       if (stamp) s0 = __builtin_amdgcn_s_memtime();
-      // the pieces of chunk `it` (issued NBUF-1 iterations ago) have landed once at most the two younger iterations'
-      // operations and the output stores issued behind those pieces are outstanding; the stores of chunk it - NBUF, issued
-      // before them, are then complete as well (vmcnt counts in issue order) -- which is what wave 4 publishes
+      // The dZ pieces of chunk `it` (issued NBUF_H-1 iterations ago) and this wave's phase pieces of chunk it + 1 (issued NBUF_H-2
+      // ago) have landed once at most the two younger iterations' operations and the output stores issued behind those pieces
+      // are outstanding; the stores of chunk it - DRAIN, issued before them, are then complete as well (vmcnt counts in issue
+      // order) -- which is what wave 4 publishes
       asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NO + 2 * (NP_D + NO)) : "memory");
+      const int nbuf = buf + 1 == NBUF_H ? 0 : buf + 1;
+      const bool decode_next = it + 1 < n_my;
       if (stamp) s1 = __builtin_amdgcn_s_memtime();
       barrier_mem();
       if (stamp) s2 = __builtin_amdgcn_s_memtime();
       // abort word of this iteration: requested now, looked at when the iteration's work is done (every wave leaves in the same
       // iteration, so the barrier counts still agree; what a doomed iteration computes and stores is garbage either way)
       const unsigned ab = lds_ld(lds_abort + (it & 1) * 4);
-      next_chunk(it + NBUF - 1);
+      next_chunk(it + NBUF_H - 1);
       const char* B = smem + (size_t)buf * BUF_HID;
       f32x16 dacc = {0};
       half8 bf[PF + 1];
-      half8 c0f, c1f;
+      float cosc[16];                              // cos of the chunk consumed now (decoded in the previous iteration)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) cosc[g] = cosn[g];
 #pragma unroll
       for (int s = 0; s < PF; ++s) bf[s] = *(const half8*)(B + s * 1024 + lane * 16);
 #pragma unroll
@@ -343,27 +399,26 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
         if (ks + PF < PKS) bf[(ks + PF) % (PF + 1)] = *(const half8*)(B + (ks + PF) * 1024 + lane * 16);
         if constexpr (!HI_ONLY) dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt_lo[ks], bf[ks % (PF + 1)], dacc, 0, 0, 0);
         dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt_hi[ks], bf[ks % (PF + 1)], dacc, 0, 0, 0);
-        if (ks == 1) piece_z(wave);
-        if (ks == 4) piece_z(4 + wave);
-        if (ks == 7) piece_z(8 + wave);
-        if (ks == 10) piece_z(12 + wave);
-        if (PIPE_COS_ON_DATA && ks == 12) piece_c(2 * wave);
-        if (PIPE_COS_ON_DATA && ks == 14) piece_c(2 * wave + 1);
-        if (ks == PKS - PF) {            // the last B fragment has been requested: cos of this wave's tile
-          c0f = *(const half8*)(B + (24 + 2 * wave) * 1024 + lane * 16);
-          c1f = *(const half8*)(B + (25 + 2 * wave) * 1024 + lane * 16);
-        }
+        if (ks == 0) piece_z(wave);
+        if (ks == 2) piece_z(4 + wave);
+        if (ks == 4) piece_z(8 + wave);
+        if (ks == 6) piece_z(12 + wave);
+        if (!PIPE_PHASE_ON_WEIGHT && ks == 8) piece_p(2 * wave);
+        if (!PIPE_PHASE_ON_WEIGHT && ks == 10) piece_p(2 * wave + 1);
+        if (ks == 12 && decode_next) read_phases(nbuf);      // the next chunk's phases, decoded behind the epilogue
         __builtin_amdgcn_sched_barrier(0);
       }
       if (stamp) { asm volatile("" :: "v"(dacc)); s3 = __builtin_amdgcn_s_memtime(); }
       // dZ_{l-1} = dH * cos (fp16, saturating) -> ring slot, fragments 2 U, 2 U + 1 of the chunk
       half8 d0, d1;
-      dz_tile(dacc, c0f, c1f, d0, d1, bs);
+      dz_tile(dacc, cosc, cosc + 8, d0, d1, bs);
       const Rsrc ro = make_rsrc(out_z, SLOT);
       buf_store(d0, ro, (2 * U) * 1024);
       buf_store(d1, ro, (2 * U + 1) * 1024);
       out_slot = out_slot + 1 == RING ? 0 : out_slot + 1;
       out_z = out_slot == 0 ? ring_out : out_z + SLOT;
+      buf = nbuf;
+      if (decode_next) decode(buf);
       if (stamp) {
         const unsigned long long s4 = __builtin_amdgcn_s_memtime();
         ph[0] += s1 - s0; ph[1] += s2 - s1; ph[2] += s3 - s2; ph[3] += s4 - s3;
@@ -423,10 +478,10 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
   const unsigned laneoff = tr_lane_offset(lane);
 
-  // gate of iteration `itn` (wave 4): its DMA (chunk itn + NBUF - 1) needs that chunk published by both producers, its output
+  // gate of iteration `itn` (wave 4): its DMA (chunk itn + NBUF_H - 1) needs that chunk published by both producers, its output
   // (slot itn % RING) needs chunk itn - RING landed in both consumers.  Normally the polled counters already say so.
   auto gate = [&](int itn) __attribute__((always_inline)) {
-    const int nx = itn + NBUF - 1;
+    const int nx = itn + NBUF_H - 1;
     const bool need_in = !TOP && nx < n_my && (int)(have_in - (unsigned)(nx + 1)) < 0;
     const bool need_out = itn >= RING && (int)(have_out - (unsigned)(itn - RING + 1)) < 0;
     if (need_in || need_out) {
@@ -442,88 +497,70 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   };
   if (gatew) {
     if (lane == 0) { lds_st(lds_abort, 0u); lds_st(lds_abort + 4, 0u); }      // the abort words are only ever SET (by a failed gate)
-    gate(-(NBUF - 1));
+    gate(-(NBUF_H - 1));
   }
 
   bool aborted = false;
-  // per iteration: the 16 H / cos pieces of the chunk -- wave 4, which also has the flag store, the poll and the gate, takes one
-  // (H 0), waves 5, 6, 7 five each (H 1 .. 7, cos 0 .. 7 in a row) --, ALL issued in front of this wave's matrix instructions.  The two waves of a SIMD share its matrix pipe: the data wave
-  // starts its 32 matrix instructions right behind the barrier, this wave's 16 should come when those are done and the data
-  // wave is in its epilogue -- the operand reads, the gate and the DMA issue in front of them take about that long.
-  // top(): counted wait, barrier, abort word, sources of the next chunk, wave 4's publication and poll.
+  // These waves issue no DMA (round 4: every piece of the workgroup goes through the data-gradient waves); wave 4 has the two
+  // vector-memory operations of the protocol per iteration (flag store, poll).  The two waves of a SIMD share its matrix pipe:
+  // the data wave starts its matrix instructions right behind the barrier, this wave's 16 follow its operand reads.
+  // top(): counted wait (wave 4), barrier, abort word, wave 4's publication and poll.
   unsigned long long tw = 0, tb = 0;       // SUNERF_PIPE_DEBUG: shader clocks in the counted wait / the barrier
   unsigned long long t_wait = 0, t_bar = 0, tl[6] = {0, 0, 0, 0, 0, 0};
   const bool stamp = a.dbg != nullptr;
-  auto weight_pieces = [&]() __attribute__((always_inline)) {
-    if (gatew) { piece_h(0); return; }
-#if PIPE_COS_ON_DATA
-    // H 1 .. 7 over waves 5, 6, 7: 2, 2, 3 pieces (the cos fragments come in through the data waves)
-    piece_h(2 * v - 1); piece_h(2 * v);
-    if (v == 3) piece_h(7);
-    return;
-#endif
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      const int g = 5 * (v - 1) + q;                       // 0 .. 14 over [H 1 .. 7, cos 0 .. 7]
-      const bool is_h = g < 7;
-      const int f = is_h ? g + 1 : g - 7;
-      dma_piece_s<1>((is_h ? nh : nc) + (size_t)f * 1024, voff, nreal ? ndst + ((is_h ? 16 : 24) + f) * 1024 : lds_dummy);
-    }
-  };
+  int pslot = NBUF_H - 1;                  // (it + NBUF_H - 1) % NBUF_H: LDS slot of the poll issued in iteration `it`
   auto top = [&](int it) __attribute__((always_inline)) {
-    const int nxt = it + NBUF - 1;
     unsigned long long sa = 0, sb = 0;
     if (stamp) sa = __builtin_amdgcn_s_memtime();
-    if (gatew) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * (1 + 2)) : "memory");
-#if PIPE_COS_ON_DATA
-    else if (v == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * 3) : "memory");
+#if PIPE_PHASE_ON_WEIGHT
+    if (gatew) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * 4) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * 2) : "memory");
 #else
-    else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * 5) : "memory");
+    if (gatew) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * 2) : "memory");      // (the poll issued NBUF_H-1 iterations ago has landed)
 #endif
     if (stamp) sb = __builtin_amdgcn_s_memtime();
     barrier_mem();
     if (stamp) { t_wait = sb; t_bar = __builtin_amdgcn_s_memtime(); tw += sb - sa; tb += t_bar - sb; }
     const unsigned ab = lds_ld(lds_abort + (it & 1) * 4);     // looked at by the caller when the iteration's work is done
-    next_chunk(nxt);
+    if (PIPE_PHASE_ON_WEIGHT) next_chunk(it + NBUF_H - 1);
     if (gatew) {
       // publish: chunk `it` has landed in this workgroup (its ring slot may be overwritten); the outputs of chunk
-      // it - NBUF are in L2 (the data waves' counted waits in front of the barrier).  One store instruction, lanes 0 and 1.
-      // Then the poll whose value is read NBUF-1 iterations on.
+      // it - DRAIN are in L2 (the data waves' counted waits in front of the barrier).  One store instruction, lanes 0 and 1.
+      // Then the poll whose value is read NBUF_H-1 iterations on.
       if (lane < 2) {
-        const int pv = lane == 0 ? it + 1 : it - NBUF + 1;
+        const int pv = lane == 0 ? it + 1 : it - DRAIN + 1;
         st_agent(lane == 0 ? my_cons : my_prod, (unsigned)(pv > 0 ? pv : 0));
       }
-      dma_poll(poll_src, lds_poll + (nxt & (NBUF - 1)) * 256);
+      pslot = pslot + 1 == NBUF_H ? 0 : pslot + 1;
+      dma_poll(poll_src, lds_poll + pslot * 256);
     }
     return ab;
   };
-  for (int it = -(NBUF - 1); it < 0; ++it) {      // prologue iterations: DMA only
+  for (int it = -(NBUF_H - 1); it < 0; ++it) {      // prologue iterations: protocol only
     const unsigned ab = top(it);
-    weight_pieces();
+    if (PIPE_PHASE_ON_WEIGHT) { piece_p(2 * v); piece_p(2 * v + 1); }
     if (ab) { aborted = true; break; }
     if (gatew && it + 1 < n_my) gate(it + 1);
   }
   unsigned long long ph[4] = {0, 0, 0, 0};      // SUNERF_PIPE_DEBUG: shader clocks in top (wait + barrier + publication) / operand reads + gate / matrix
   tw = 0; tb = 0;
+  int buf = 0;                                   // it % NBUF_H
   for (int it = 0; it < (aborted ? 0 : n_my); ++it) {
-    const int buf = it & (NBUF - 1);
     unsigned long long s0 = 0, s1 = 0, s2 = 0;
     if (stamp) s0 = __builtin_amdgcn_s_memtime();
     const unsigned ab = top(it);
     if (stamp) s1 = __builtin_amdgcn_s_memtime();
-    // operand bases of this wave's block: row tiles r0.. of the dZ fragments, column tiles c0.. of the H fragments; the tile
-    // and k-step parts of the addresses are immediates
+    // operand bases of this wave's block: row tiles r0.. of the dZ fragments, column tiles c0.. of the H fragments (fp16 sin,
+    // decoded in place by the data-gradient waves one iteration ago); the tile and k-step parts of the addresses are immediates
     const unsigned bufA = lds0 + buf * BUF_HID + laneoff + r0 * 2048, bufB = lds0 + buf * BUF_HID + laneoff + 16 * 1024 + c0 * 2048;
     // operands of the two k-steps: A = dZ^T row tiles r0 .. r0 + 3, B = H column tiles c0, c0 + 1; registers v80 .. v127
     half8 A0[4], B0[2], A1[4], B1[2];
     TR_FIXED(80, 81, 82, 83, 0 * 2048, A0[0], bufA); TR_FIXED(84, 85, 86, 87, 1 * 2048, A0[1], bufA);
     TR_FIXED(88, 89, 90, 91, 2 * 2048, A0[2], bufA); TR_FIXED(92, 93, 94, 95, 3 * 2048, A0[3], bufA);
     TR_FIXED(96, 97, 98, 99, 0 * 2048, B0[0], bufB); TR_FIXED(100, 101, 102, 103, 1 * 2048, B0[1], bufB);
-    weight_pieces();
     typedef __attribute__((address_space(3))) v4u lds_v4u;
     v4u pw = {0, 0, 0, 0};
-    if (gatew) pw = *(const lds_v4u*)(uintptr_t)(lds_poll + buf * 256);     // the poll that landed with this iteration's chunk
+    if (gatew) pw = *(const lds_v4u*)(uintptr_t)(lds_poll + buf * 256);     // the poll issued NBUF_H-1 iterations ago
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (gatew) {     // -> gate of the next iteration (in the shadow of the operand reads' wait)
       asm volatile("" : "+v"(pw));
@@ -555,9 +592,12 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
         const half8 af = ks ? A1[i] : A0[i];
         mfma_agpr(acc[i][0], af, bf0);
         mfma_agpr(acc[i][1], af, bf1);
+        if (PIPE_PHASE_ON_WEIGHT && ks == 0 && i == 0) piece_p(2 * v);
+        if (PIPE_PHASE_ON_WEIGHT && ks == 0 && i == 2) piece_p(2 * v + 1);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    buf = buf + 1 == NBUF_H ? 0 : buf + 1;
     if (stamp) {
       const unsigned long long s3 = __builtin_amdgcn_s_memtime();
       ph[0] += s1 - s0; ph[1] += s2 - s1; ph[2] += s3 - s2;
@@ -610,7 +650,7 @@ __device__ __forceinline__ void in_stage(const PipeArgs& a, char* smem, int P, i
     return;
   }
   const int n_act = a.n_linear - 1, n_links = n_act - 1;
-  const StashLayout SL(PD, a.n_linear);
+  const StashLayout SL(PD, a.n_linear, true);
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   const unsigned lds_dummy = lds0 + NBUF * BUF_IN;
   const unsigned lds_poll = lds_dummy + 1024;
@@ -723,7 +763,7 @@ __global__ __launch_bounds__(WG, 1) void bwd_pipe_kernel(PipeArgs a) {
 
   // ---- start-up: everybody resident, every class (blockIdx % 8) on one XCD ----
   // (no static __shared__: it would shift the dynamic region off its 16-byte alignment)
-  const unsigned start_ok = (unsigned)(uintptr_t)smem + NBUF * BUF_HID + 1024 + NBUF * 256 + 32;
+  const unsigned start_ok = (unsigned)(uintptr_t)smem + NBUF_H * BUF_HID + 1024 + NBUF_H * 256 + 32;
   if (tid == 0) {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -766,17 +806,19 @@ __global__ __launch_bounds__(WG, 1) void bwd_pipe_kernel(PipeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// prologue: dZ of the last activation layer (-> dz_top) and dW / db of the out layer, one streaming pass over g_raw and the
-// H / cos fragments of the last activation layer
+// prologue: dZ of the last activation layer (-> dz_top), its db, and dW / db of the out layer: one streaming pass over g_raw and
+// the PHASE fragments of the last activation layer (16 KiB per chunk in, 16 KiB out).  Wave w owns tiles 2 w, 2 w + 1 of that
+// layer: it fetches their four phase fragments itself and decodes them -- cos -> registers for dZ = (W_out^T g) cos, sin -> fp16
+// written back in place, which is the LDS image its own transposed reads for dW_out take.
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG_PRE, 1) void bwd_prologue_kernel(PipeArgs a) {
-  constexpr int PW = 8, NO = 4;
+  constexpr int PW = 4, NO = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 31, h = lane >> 5;
   const int n_act = a.n_linear - 1;
-  const StashLayout SL(PD, a.n_linear);
+  const StashLayout SL(PD, a.n_linear, true);
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   const unsigned lds_dummy = lds0 + NBUF * BUF_PRE;
   const float gscale = sunerf_gscale(*a.g_absmax_bits);
@@ -799,11 +841,13 @@ __global__ __launch_bounds__(WG_PRE, 1) void bwd_prologue_kernel(PipeArgs a) {
   for (int g = 0; g < 16; ++g) { bs[0][g] = 0.f; bs[1][g] = 0.f; }
   float gsum0 = 0.f, gsum1 = 0.f;       // wave 0: db of the out layer = sum of the (scaled) fp32 g_raw itself
   const size_t act_chunk = SL.chunk_bytes();
-  const char* srcH0 = a.act_stash + SL.h_off(n_act - 1) + lane * 16;
-  const char* srcC0 = a.act_stash + SL.c_off(n_act - 1) + lane * 16;
+  const char* srcP0 = a.act_stash + SL.h_off(n_act - 1) + (size_t)(4 * wave) * 1024 + lane * 16;     // this wave's four fragments
   const unsigned laneoff = tr_lane_offset(lane);
   char* scratch = a.rings + (size_t)a.NP * (n_act - 1) * RING * SLOT + ((size_t)blockIdx.x * 4 + wave) * 2048;
+  typedef __attribute__((address_space(3))) v4u lds_v4u;
+  typedef __attribute__((address_space(3))) half8 lds_half8;
 
+  // LDS image of a chunk: [16 phase fragments -> fp16 sin][dZ_out operand tile, 2 fragments][g_raw, 256 B]
   auto issue_chunk = [&](int c, int buf) __attribute__((always_inline)) {
     const bool real = c < n_my;
     const int64_t g = real ? cbeg + c : safe;
@@ -814,14 +858,11 @@ __global__ __launch_bounds__(WG_PRE, 1) void bwd_prologue_kernel(PipeArgs a) {
       // vmcnt waits rely on that).  A compiler-visible load here would drain the whole DMA queue with vmcnt(0) every chunk.
       const int64_t ray = g / a.n_chunks;
       const int c32 = (int)(g % a.n_chunks) * 32;
-      if (c32 + (lane >> 1) < a.S) dma_poll((const unsigned*)(a.g_raw + ((size_t)ray * a.S + c32) * 2 + lane), real ? dst0 + 34 * 1024 : lds_dummy);
+      if (c32 + (lane >> 1) < a.S) dma_poll((const unsigned*)(a.g_raw + ((size_t)ray * a.S + c32) * 2 + lane), real ? dst0 + 18 * 1024 : lds_dummy);
     }
 #pragma unroll
-    for (int k = 0; k < PW; ++k) {
-      const int p = 4 * k + wave;
-      if (k < 4) dma_piece<1>(srcH0 + (size_t)g * act_chunk + (size_t)p * 1024, real ? dst0 + p * 1024 : lds_dummy);
-      else dma_piece<1>(srcC0 + (size_t)g * act_chunk + (size_t)(p - 16) * 1024, real ? dst0 + p * 1024 : lds_dummy);
-    }
+    for (int k = 0; k < PW; ++k)
+      dma_piece<1>(srcP0 + (size_t)g * act_chunk + (size_t)k * 1024, real ? dst0 + (4 * wave + k) * 1024 : lds_dummy);
   };
 
   for (int it = -(NBUF - 1); it < n_my; ++it) {
@@ -830,24 +871,33 @@ __global__ __launch_bounds__(WG_PRE, 1) void bwd_prologue_kernel(PipeArgs a) {
     if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NO + 2 * (PW + NO + 1)) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NO + 2 * (PW + NO)) : "memory");
     half8 dzo = {0, 0, 0, 0, 0, 0, 0, 0};
+    float cs[2][16];
     if (it >= 0) {
+      // this wave's own phase pieces of the chunk have landed (counted wait above): decode -- cos stays here, fp16 sin goes back
+      // to the same 16 bytes
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const unsigned at = lds0 + buf * BUF_PRE + (4 * wave + f) * 1024 + lane * 16;
+        const v4u p = *(const lds_v4u*)(uintptr_t)at;
+        float sn[8];
+        decode_phases(p, sn, cs[f >> 1] + 8 * (f & 1));
+        *(lds_half8*)(uintptr_t)at = to_half8(sn);
+      }
       // g_raw of this lane's sample -> B fragment of the out layer's dZ (features 0 / 1 = d loss / d raw[..., 0 / 1]) and the
       // A-operand tile of the out layer's weight gradient (fragment-order index 16 s + 8 h + e -> s = 0, h = 0, e = 0 / 1)
       const int64_t chunk = cbeg + it;
-      const int64_t ray = chunk / a.n_chunks;
       const int c = (int)(chunk % a.n_chunks);
       const int i = 32 * c + n;
-      (void)ray;
       if (h == 0 && i < a.S) {
-        const f32x2 g = *(const f32x2*)(smem + (size_t)buf * BUF_PRE + 34 * 1024 + n * 8);
+        const f32x2 g = *(const f32x2*)(smem + (size_t)buf * BUF_PRE + 18 * 1024 + n * 8);
         const float g0 = g[0] * gscale, g1 = a.d_out > 1 ? g[1] * gscale : 0.f;
         dzo[0] = (_Float16)g0;
         dzo[1] = (_Float16)g1;
         gsum0 += g0;
         gsum1 += g1;
       }
-      if (wave == 0) *(half8*)(smem + (size_t)buf * BUF_PRE + 32 * 1024 + lane * 16) = dzo;
-      else if (wave == 1) *(half8*)(smem + (size_t)buf * BUF_PRE + 33 * 1024 + lane * 16) = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (wave == 0) *(half8*)(smem + (size_t)buf * BUF_PRE + 16 * 1024 + lane * 16) = dzo;
+      else if (wave == 1) *(half8*)(smem + (size_t)buf * BUF_PRE + 17 * 1024 + lane * 16) = (half8){0, 0, 0, 0, 0, 0, 0, 0};
     }
     barrier_mem();
     issue_chunk(nxt, nxt & (NBUF - 1));
@@ -858,7 +908,6 @@ __global__ __launch_bounds__(WG_PRE, 1) void bwd_prologue_kernel(PipeArgs a) {
       for (int k = 0; k < NO; ++k) buf_store(zero, sc, (k & 1) * 1024);
       continue;
     }
-    const char* B = smem + (size_t)buf * BUF_PRE;
     // ---- dZ_top tiles 2 w, 2 w + 1: (W_out^T g) * cos ----
     const Rsrc ro = make_rsrc(a.dz_top + (size_t)(cbeg + it) * SLOT, SLOT);
 #pragma unroll
@@ -866,15 +915,13 @@ __global__ __launch_bounds__(WG_PRE, 1) void bwd_prologue_kernel(PipeArgs a) {
       const int U = 2 * wave + t;
       f32x16 d = {0};
       d = __builtin_amdgcn_mfma_f32_32x32x16_f16(aT[t], dzo, d, 0, 0, 0);
-      const half8 c0f = *(const half8*)(B + (16 + 2 * U) * 1024 + lane * 16);
-      const half8 c1f = *(const half8*)(B + (17 + 2 * U) * 1024 + lane * 16);
       half8 d0, d1;
-      dz_tile(d, c0f, c1f, d0, d1, bs[t]);
+      dz_tile(d, cs[t], cs[t] + 8, d0, d1, bs[t]);
       buf_store(d0, ro, (2 * U) * 1024);
       buf_store(d1, ro, (2 * U + 1) * 1024);
     }
-    // ---- out layer weight gradient: row tile 0 (outputs 0 / 1), column tiles 2 w, 2 w + 1 of H_top ----
-    const unsigned bufH = lds0 + buf * BUF_PRE + laneoff, bufA = bufH + 32 * 1024;
+    // ---- out layer weight gradient: row tile 0 (outputs 0 / 1), column tiles 2 w, 2 w + 1 of H_top (decoded above) ----
+    const unsigned bufH = lds0 + buf * BUF_PRE + laneoff, bufA = bufH + 16 * 1024;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       half4 alo, ahi, blo[2], bhi[2];
@@ -986,7 +1033,7 @@ extern "C" int sunerf_mlp_backward_pipe(int d_filter, int n_linear, int d_out, c
   // sticky block in front of it is only ever OR-ed into (reduce_grads_kernel) and belongs to the caller
   if ((e = hipMemsetAsync(ws + L.ctrl, 0, L.rings - L.ctrl, st)) != hipSuccess) return (int)e;
   const size_t lds_pre = (size_t)NBUF * BUF_PRE + 1024;
-  const size_t lds_pipe = (size_t)NBUF * BUF_HID + 1024 + NBUF * 256 + 64;
+  const size_t lds_pipe = (size_t)NBUF_H * BUF_HID + 1024 + NBUF_H * 256 + 64;
   if ((e = hipFuncSetAttribute((const void*)bwd_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pre)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)bwd_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe)) != hipSuccess) return (int)e;
   if ((e = hipFuncSetAttribute((const void*)bwd_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe)) != hipSuccess) return (int)e;

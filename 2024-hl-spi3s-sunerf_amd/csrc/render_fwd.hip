@@ -45,6 +45,7 @@ struct RenderArgs {
   float* regularization;
   float reg_radius;
   char* stash;
+  int stash_phase;   // 1: the stash takes 16-bit phases (SUNERF_STASH_PHASE) instead of fp16 sin + cos fragments
   char* scratch;   // d_filter = 512: per-wave activation scratch, gridDim.x * 4 waves * (D/16) * 2 KiB
 };
 
@@ -126,7 +127,7 @@ constexpr int XL_SHIFT = 17;      // log2 of the factor on the fp8 remainder ope
 #ifndef SUNERF_ABL_NO_L8
 #define SUNERF_ABL_NO_L8 0        // the remainder's scale + fp8 conversion (3 vector instructions per pair micro-op) not issued
 #endif
-template <bool STASH>
+template <int STASH>
 __device__ __forceinline__ void epi_stage_a(const f32x16& acc, int p, PairTmp& t) {
 #if SUNERF_ABL_NO_TRANS
   t.s0 = __builtin_amdgcn_fractf(acc[2 * p]);
@@ -138,13 +139,18 @@ __device__ __forceinline__ void epi_stage_a(const f32x16& acc, int p, PairTmp& t
   t.s0 = __builtin_amdgcn_sinf(acc[2 * p]);
   t.s1 = __builtin_amdgcn_sinf(acc[2 * p + 1]);
   asm volatile("" : "+v"(t.s0), "+v"(t.s1));
-  if (STASH) {   // d sin(z)/dz for the backward pass
+  if (STASH == 1) {   // d sin(z)/dz for the backward pass
     t.c0 = __builtin_amdgcn_cosf(acc[2 * p]);
     t.c1 = __builtin_amdgcn_cosf(acc[2 * p + 1]);
     asm volatile("" : "+v"(t.c0), "+v"(t.c1));
   }
+  if (STASH == 2) {   // phase of the pre-activation (revolutions, [0, 1)): the pipelined backward recovers sin AND cos from it
+    t.c0 = __builtin_amdgcn_fractf(acc[2 * p]);
+    t.c1 = __builtin_amdgcn_fractf(acc[2 * p + 1]);
+    asm volatile("" : "+v"(t.c0), "+v"(t.c1));
+  }
 }
-template <bool STASH, bool HALF = false>
+template <int STASH, bool HALF = false>
 __device__ __forceinline__ void epi_stage_b(PairTmp& t) {
   const f32x2 sv = {t.s0, t.s1};
   t.hi = __builtin_convertvector(sv, half2v);   // one v_cvt_pk_f16_f32 (round to nearest even)
@@ -156,9 +162,13 @@ __device__ __forceinline__ void epi_stage_b(PairTmp& t) {
     asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(t.r0) : "v"(t.hi), "v"(t.s0));
     asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t.r1) : "v"(t.hi), "v"(t.s1));
   }
-  if (STASH) {
+  if (STASH == 1) {
     const f32x2 cv = {t.c0, t.c1};
     t.cpk = __builtin_convertvector(cv, half2v);
+    asm volatile("" : "+v"(t.cpk));
+  }
+  if (STASH == 2) {   // two 16-bit phase codes in one dword (v_cvt_pknorm_u16_f32: round(65535 f))
+    t.cpk = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pknorm_u16(t.c0, t.c1));
     asm volatile("" : "+v"(t.cpk));
   }
 }
@@ -166,7 +176,7 @@ __device__ __forceinline__ void epi_stage_b(PairTmp& t) {
 // from an H fragment to the matching cos fragment.  SPILL_OUT (d_filter = 512): the two activation sets do not fit the
 // register file together, so the finished hi / lo fragments go to this wave's global scratch at `sc`
 // ([fragment][hi 1 KiB | lo 1 KiB]) instead of staying in registers; they come back as the next layer's input.
-template <bool STASH, bool SPILL_OUT, bool HALF = false>
+template <int STASH, bool SPILL_OUT, bool HALF = false>
 __device__ __forceinline__ void epi_stage_c(const PairTmp& t, int p, half8& hi0, half8& lo0, half8& hi1, half8& lo1,
                                             half8& ch0, half8& ch1, Rsrc st, int st_off, int cos_delta, Rsrc sc, int sc_off) {
   if (p < 4) { hi0[2 * p] = t.hi[0]; hi0[2 * p + 1] = t.hi[1]; }
@@ -185,12 +195,14 @@ __device__ __forceinline__ void epi_stage_c(const PairTmp& t, int p, half8& hi0,
   if (p == 3) {
     if (SPILL_OUT) { buf_store(hi0, sc, sc_off); buf_store(lo0, sc, sc_off + 1024); }
     else { pin_agpr(hi0); if (!HALF) pin_agpr(lo0); }
-    if (STASH) { buf_store_nt(hi0, st, st_off); buf_store_nt(ch0, st, st_off + cos_delta); }
+    if (STASH == 1) { buf_store_nt(hi0, st, st_off); buf_store_nt(ch0, st, st_off + cos_delta); }
+    if (STASH == 2) buf_store_nt(ch0, st, st_off);          // one phase fragment instead of a sin and a cos fragment
   }
   if (p == 7) {
     if (SPILL_OUT) { buf_store(hi1, sc, sc_off + 2048); buf_store(lo1, sc, sc_off + 3072); }
     else { pin_agpr(hi1); if (!HALF) pin_agpr(lo1); }
-    if (STASH) { buf_store_nt(hi1, st, st_off + 1024); buf_store_nt(ch1, st, st_off + 1024 + cos_delta); }
+    if (STASH == 1) { buf_store_nt(hi1, st, st_off + 1024); buf_store_nt(ch1, st, st_off + 1024 + cos_delta); }
+    if (STASH == 2) buf_store_nt(ch1, st, st_off + 1024);
   }
 }
 
@@ -297,7 +309,7 @@ struct Mlp {
   // SPILL_OUT: the epilogue's fragments go to scratch at `sc_out` (see epi_stage_c).  RELOAD (last tile of a d = 512
   // hidden layer): k-step s is the last reader of input fragment s, so it is refilled right there from `sc_in` with
   // fragment s of the layer's OUTPUT (written to scratch at least one tile earlier) = the next layer's input.
-  template <int KIN, int T0, bool HAS_PREV, int RS0, bool STASH, bool SPILL_OUT = false, bool RELOAD = false>
+  template <int KIN, int T0, bool HAS_PREV, int RS0, int STASH, bool SPILL_OUT = false, bool RELOAD = false>
   static __device__ __forceinline__ f32x16 tile(Ring<D>& ring, Pipe& p, f32x16 acc, half8* xhi, half8* xlo,
                                                 const f32x16& prev, half8& yh0, half8& yl0, half8& yh1, half8& yl1,
                                                 Rsrc st, int st_off, int cos_delta, Rsrc sc, int sc_out_off = 0) {
@@ -355,7 +367,7 @@ struct Mlp {
         if (phase == ACQ) {                                          // the reads below cross into the next page
           // vector-memory operations certainly issued after the last piece of the page being acquired (besides the
           // pieces of the following page): the epilogue's stores, which fall into the first page cycle of a tile
-          constexpr int STORES = (HAS_PREV && KIN >= 16 && PER == 1) ? ((SPILL_OUT ? 4 : 0) + (STASH ? 4 : 0)) : 0;
+          constexpr int STORES = (HAS_PREV && KIN >= 16 && PER == 1) ? ((SPILL_OUT ? 4 : 0) + (STASH == 1 ? 4 : STASH == 2 ? 2 : 0)) : 0;
           if (s < 16) ring.template acquire<STORES>();
           else ring.template acquire<0>();
         }
@@ -391,7 +403,7 @@ struct Mlp {
   // whose epilogue (into that layer's output set = our X, fragments 2*NT-2, 2*NT-1) overlaps our first tile: those
   // fragments are only read by our last two k-steps.  Returns our own last accumulator the same way.
   // st_prev / st_own: this lane's stash address of fragment 0 of the previous / of this layer's H block (training).
-  template <int KIN, bool HAS_CARRY, int RSL0, bool STASH>
+  template <int KIN, bool HAS_CARRY, int RSL0, int STASH>
   static __device__ __forceinline__ f32x16 layer(Ring<D>& ring, Pipe& p, const float* bias, int h, half8* xhi, half8* xlo,
                                                  half8* yhi, half8* ylo, const f32x16& carry, Rsrc st, int st_prev, int st_own,
                                                  Rsrc scratch) {
@@ -451,7 +463,7 @@ struct Mlp {
     return prev;
   }
 
-  template <bool STASH>
+  template <int STASH>
   static __device__ __forceinline__ f32x16 out_layer(Ring<D>& ring, Pipe& p, const float* bias, int h, half8* xhi,
                                                      half8* xlo, const f32x16& carry, Rsrc st, int st_prev, Rsrc scratch) {
     constexpr int XL = 2 * NT - 2;
@@ -485,7 +497,7 @@ __device__ __forceinline__ void pin_agpr8(v8i& f) { asm volatile("" : "+a"(f)); 
 // SPILL_OUT (d = 512: one set of fp16 heads, two sets of fp8 operands): the finished fp16 fragment goes to this wave's
 // scratch (1 KiB per fragment, fragment order) instead of registers, the fp8 group stays in registers like at d <= 256;
 // `th` collects the fragment under construction.
-template <bool STASH, bool SPILL_OUT = false>
+template <int STASH, bool SPILL_OUT = false>
 __device__ __forceinline__ void epi_stage_c8(const PairTmp& t, int p, int FP, half8* yhi, v8i* yh8, v8i* yl8, v8i& w8h,
                                              v8i& w8l, half8& ch0, half8& ch1, Rsrc st, int st_off, int cos_delta,
                                              Rsrc sc = Rsrc(), half8* th = nullptr) {
@@ -537,10 +549,11 @@ __device__ __forceinline__ void epi_stage_c8(const PairTmp& t, int p, int FP, ha
         pin_agpr8(yh8[g]); pin_agpr8(yl8[g]);
       }
     }
-    if (STASH) {
+    if (STASH == 1) {
       buf_store_nt(hf, st, st_off + (p >> 2) * 1024);
       buf_store_nt(p < 4 ? ch0 : ch1, st, st_off + (p >> 2) * 1024 + cos_delta);
     }
+    if (STASH == 2) buf_store_nt(p < 4 ? ch0 : ch1, st, st_off + (p >> 2) * 1024);
   }
 }
 __device__ __forceinline__ v8i buf_load8(Rsrc r, int off) {   // two 16-byte halves of an fp8 operand (1 KiB apart)
@@ -622,7 +635,7 @@ struct Mlp8 : Mlp<D> {
   // SPILL_OUT / RELOAD (d = 512): the pending epilogue writes to scratch `scr`; in the LAST tile of a layer every operand
   // of the single register set is refilled, right behind its last use, with the layer's own output from scratch (requests
   // are committed to the operand registers a few instructions later so the wave never waits for the round trip).
-  template <bool HAS_PREV, int RS0, bool STASH, bool SPILL_OUT = false, bool RELOAD = false>
+  template <bool HAS_PREV, int RS0, int STASH, bool SPILL_OUT = false, bool RELOAD = false>
   static __device__ __forceinline__ f32x16 tile8(Ring<D>& ring, Pipe& p, Pipe8& q, f32x16 acc, half8* xhi,
                                                  v8i* xh8, v8i* xl8, const Scales sc, const f32x16& prev,
                                                  f32x16& pc /* in: correction accumulator of prev; out: ours */, int FP,
@@ -761,7 +774,7 @@ struct Mlp8 : Mlp<D> {
   }
 
   // in-layer tile (6 k-steps, classic hi | lo weights and encoding operands) with the fp8c epilogue format
-  template <int T0, bool HAS_PREV, int RS0, bool STASH, bool SPILL_OUT = false>
+  template <int T0, bool HAS_PREV, int RS0, int STASH, bool SPILL_OUT = false>
   static __device__ __forceinline__ f32x16 tile_in(Ring<D>& ring, Pipe& p, f32x16 acc, const half8* xhi, const half8* xlo,
                                                    const f32x16& prev, int FP, half8* yhi, v8i* yh8, v8i* yl8, v8i& w8h,
                                                    v8i& w8l, Rsrc st, int st_off, int cos_delta, Rsrc scr = Rsrc()) {
@@ -821,7 +834,7 @@ struct Mlp8 : Mlp<D> {
 
   // in layer: encoding (6 k-steps, hi | lo) -> y set (fp8c format); returns the last tile's accumulator (its epilogue is
   // carried into the first hidden tile)
-  template <bool STASH>
+  template <int STASH>
   static __device__ __forceinline__ f32x16 in_layer(Ring<D>& ring, Pipe& p, const float* bias, int h, const half8* ehi,
                                                     const half8* elo, half8* yhi, v8i* yh8, v8i* yl8, v8i& w8h, v8i& w8l,
                                                     Rsrc st, int st_own, Rsrc scr = Rsrc()) {
@@ -859,7 +872,7 @@ struct Mlp8 : Mlp<D> {
 
   // hidden layer: x set -> y set; `carry` = accumulator of the layer above's last tile (its epilogue completes x while our
   // first tile runs: fragments 2 NT - 2, 2 NT - 1 = k-steps KS - 2, KS - 1)
-  template <bool STASH>
+  template <int STASH>
   static __device__ __forceinline__ f32x16 hidden_layer(Ring<D>& ring, Pipe& p, Pipe8& q, const float* bias, int h,
                                                         const Scales sc, half8* xhi, v8i* xh8, v8i* xl8, half8* yhi,
                                                         v8i* yh8, v8i* yl8, v8i& w8h, v8i& w8l, const f32x16& carry, f32x16& pc,
@@ -905,7 +918,7 @@ struct Mlp8 : Mlp<D> {
     return prev;
   }
 
-  template <bool STASH>
+  template <int STASH>
   static __device__ __forceinline__ f32x16 out_layer(Ring<D>& ring, Pipe& p, Pipe8& q, const float* bias, int h,
                                                      const Scales sc, half8* xhi, v8i* xh8, v8i* xl8, v8i& w8h, v8i& w8l,
                                                      const f32x16& carry, f32x16& pc, Rsrc st, int st_prev) {
@@ -916,13 +929,13 @@ struct Mlp8 : Mlp<D> {
   }
 };
 
-template <int D, bool STASH, bool FP8C, bool HALF = false>
+template <int D, int STASH, bool FP8C, bool HALF = false>
 __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
   static_assert(!HALF || !FP8C, "HALF: classic stream format");
   using M = Mlp<D, HALF>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const PackedLayout L(D, a.n_linear);
-  const StashLayout SL(D, a.n_linear);
+  const StashLayout SL(D, a.n_linear, STASH == 2);
   char* slot = smem;                                            // ring of NSLOT weight pages
   float* bias = (float*)(smem + (size_t)Ring<D>::RING);          // n_bias floats
   const int tid = threadIdx.x;
@@ -1265,7 +1278,7 @@ __global__ __launch_bounds__(THREADS, 1) void render_fwd_kernel(RenderArgs a) {
 #endif
 }
 
-template <int D, bool STASH, bool FP8C, bool HALF = false>
+template <int D, int STASH, bool FP8C, bool HALF = false>
 int launch_render_t(const RenderArgs& a, hipStream_t stream) {
   const PackedLayout L(D, a.n_linear);
   const size_t lds = (size_t)Ring<D>::RING + L.n_bias() * 4;
@@ -1286,11 +1299,19 @@ int launch_render_t(const RenderArgs& a, hipStream_t stream) {
 }
 template <int D>
 int launch_render(const RenderArgs& a, int precision, hipStream_t stream) {
+  if constexpr (D == 256) {        // the 16-bit phase stash is what the pipelined backward reads, and that exists at this width only
+    if (a.stash && a.stash_phase) {
+      if (precision == SUNERF_PRECISION_FAST) return launch_render_t<D, 2, true>(a, stream);
+      if (precision == SUNERF_PRECISION_HALF) return launch_render_t<D, 2, false, true>(a, stream);
+      return launch_render_t<D, 2, false>(a, stream);
+    }
+  }
+  if (a.stash && a.stash_phase) return SUNERF_E_UNSUPPORTED;
   if (precision == SUNERF_PRECISION_FAST)
-    return a.stash ? launch_render_t<D, true, true>(a, stream) : launch_render_t<D, false, true>(a, stream);
+    return a.stash ? launch_render_t<D, 1, true>(a, stream) : launch_render_t<D, 0, true>(a, stream);
   if (precision == SUNERF_PRECISION_HALF)
-    return a.stash ? launch_render_t<D, true, false, true>(a, stream) : launch_render_t<D, false, false, true>(a, stream);
-  return a.stash ? launch_render_t<D, true, false>(a, stream) : launch_render_t<D, false, false>(a, stream);
+    return a.stash ? launch_render_t<D, 1, false, true>(a, stream) : launch_render_t<D, 0, false, true>(a, stream);
+  return a.stash ? launch_render_t<D, 1, false>(a, stream) : launch_render_t<D, 0, false>(a, stream);
 }
 
 }  // namespace
@@ -1301,18 +1322,19 @@ extern "C" size_t sunerf_render_workspace_bytes(int d_filter) {
   return d_filter > 256 ? (size_t)1024 * 4 * (size_t)(d_filter / 16) * 2048 : 0;
 }
 
-extern "C" size_t sunerf_act_stash_bytes(int64_t n_rays, int n_samples, int d_filter, int n_linear) {
+extern "C" size_t sunerf_act_stash_bytes(int64_t n_rays, int n_samples, int d_filter, int n_linear, int stash_format) {
   if (n_rays < 0 || n_samples < 1 || d_filter < 32 || d_filter % 32 || n_linear < 2) return 0;
+  if (stash_format != SUNERF_STASH_FP16 && !(stash_format == SUNERF_STASH_PHASE && d_filter == 256)) return 0;
   const int64_t chunks = n_rays * ((n_samples + 31) / 32) + 1;   // + one spare chunk for ragged groups
-  return (size_t)chunks * StashLayout(d_filter, n_linear).chunk_bytes();
+  return (size_t)chunks * StashLayout(d_filter, n_linear, stash_format == SUNERF_STASH_PHASE).chunk_bytes();
 }
 
 extern "C" int sunerf_emission_render_fwd(const void* packed, int d_filter, int n_linear, int precision, const float* rays_o,
                                           const float* rays_d, const float* times, const float* z_vals,
                                           int64_t n_rays, int n_samples, float* image, float* weights,
                                           float* absorption, float* raw, float* height_map, float* absorption_map,
-                                          float* regularization, float reg_radius, void* act_stash, void* workspace,
-                                          size_t workspace_bytes, void* stream) {
+                                          float* regularization, float reg_radius, void* act_stash, int stash_format,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
   if (n_rays < 0 || n_samples < 2) return SUNERF_E_BADARG;
   if (n_linear < 2 || n_linear > SUNERF_MAX_LAYERS) return SUNERF_E_UNSUPPORTED;
   if (precision != SUNERF_PRECISION_FAST && precision != SUNERF_PRECISION_EXACT && precision != SUNERF_PRECISION_HALF)
@@ -1324,6 +1346,8 @@ extern "C" int sunerf_emission_render_fwd(const void* packed, int d_filter, int 
   a.n_rays = n_rays; a.S = n_samples; a.n_linear = n_linear; a.image = image; a.weights = weights;
   a.absorption = absorption; a.raw = raw; a.height_map = height_map; a.absorption_map = absorption_map;
   a.regularization = regularization; a.reg_radius = reg_radius; a.stash = (char*)act_stash;
+  if (stash_format != SUNERF_STASH_FP16 && stash_format != SUNERF_STASH_PHASE) return SUNERF_E_BADARG;
+  a.stash_phase = stash_format == SUNERF_STASH_PHASE;
   a.scratch = (char*)workspace;
   if (workspace_bytes < sunerf_render_workspace_bytes(d_filter)) return SUNERF_E_WORKSPACE;
   switch (d_filter) {
@@ -1336,8 +1360,8 @@ extern "C" int sunerf_emission_render_fwd(const void* packed, int d_filter, int 
 }
 
 extern "C" int sunerf_mlp_points_fwd(const void* packed, int d_filter, int n_linear, int precision, const float* points,
-                                     int64_t n_points, float* raw, void* act_stash, void* workspace, size_t workspace_bytes,
-                                     void* stream) {
+                                     int64_t n_points, float* raw, void* act_stash, int stash_format, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
   if (n_points < 0 || n_points % 32) return SUNERF_E_BADARG;       // whole 32-point chunks (callers pad)
   if (n_linear < 2 || n_linear > SUNERF_MAX_LAYERS) return SUNERF_E_UNSUPPORTED;
   if (precision != SUNERF_PRECISION_FAST && precision != SUNERF_PRECISION_EXACT && precision != SUNERF_PRECISION_HALF)
@@ -1349,6 +1373,8 @@ extern "C" int sunerf_mlp_points_fwd(const void* packed, int d_filter, int n_lin
   a.n_rays = n_points / 32; a.S = 32; a.n_linear = n_linear; a.image = nullptr; a.weights = nullptr; a.absorption = nullptr;
   a.raw = raw; a.height_map = nullptr; a.absorption_map = nullptr; a.regularization = nullptr; a.reg_radius = 0.f;
   a.stash = (char*)act_stash; a.scratch = (char*)workspace;
+  if (stash_format != SUNERF_STASH_FP16 && stash_format != SUNERF_STASH_PHASE) return SUNERF_E_BADARG;
+  a.stash_phase = stash_format == SUNERF_STASH_PHASE;
   if (workspace_bytes < sunerf_render_workspace_bytes(d_filter)) return SUNERF_E_WORKSPACE;
   switch (d_filter) {
     case 64: return launch_render<64>(a, precision, (hipStream_t)stream);

@@ -87,18 +87,29 @@ struct PackedLayout {
 constexpr int SUNERF_GROUP_BYTES = 8192;
 
 // Activation stash written by the training forward pass and read by the backward kernels.  Everything is kept in
-// MFMA B-fragment order (1 KiB per fragment: lane l = 16 bytes = 8 fp16 at offset 16 l; element e of lane half h of
+// MFMA B-fragment order (1 KiB per fragment: lane l = 16 bytes = 8 x 16 bit at offset 16 l; element e of lane half h of
 // fragment s is feature kmap_hidden(s, h, e) of sample l & 31), i.e. exactly the registers the forward kernel holds,
-// so a fragment is one fully coalesced 1 KiB store.  Per 32-sample chunk:
-//   [enc : 6 fragments, fp16(hi) of the encoded input (kmap_encoding order)]
-//   for every activation layer l = 0 .. n_linear-2:  [H_l : D/16 fragments, fp16(sin)] [C_l : D/16 fragments, fp16(cos)]
+// so a fragment is one fully coalesced 1 KiB store.  Per 32-sample chunk, two formats (include/sunerf_hip.h: SUNERF_STASH_*):
+//   FP16  [enc : 6 fragments, fp16(hi) of the encoded input (kmap_encoding order)]
+//         for every activation layer l = 0 .. n_linear-2:  [H_l : D/16 fragments, fp16(sin)] [C_l : D/16 fragments, fp16(cos)]
+//         -- what the two-kernel backward (render_bwd.hip, wgrad.hip) reads: 8.2 KB per sample of an 8 x 256 network
+//   PHASE [enc : 6 fragments] and for every activation layer [P_l : D/16 fragments, 16-bit PHASE of the pre-activation]  [r4]
+//         -- what the layer-pipelined backward (bwd_pipe.hip) reads: 4.1 KB per sample.  The phase is frac(z / 2 pi) in [0, 1)
+//         as an unsigned normalised 16-bit code (v_cvt_pknorm_u16_f32: round(65535 f)).  The backward needs sin(z) (weight
+//         gradients) AND cos(z) (data gradients): one phase gives both to 2^-17 of a revolution = 4.8e-5 absolute (the fp16
+//         sin / cos fragments carry 2^-12 relative each), in half the bytes.  Decoding is v_cvt_f32_u32 on a 16-bit half + v_mul +
+//         v_sin / v_cos -- done by the data-gradient waves of bwd_pipe.hip in the time they used to wait at the barrier.
 struct StashLayout {
   int KS, n_act;
-  __host__ __device__ StashLayout(int d, int n_linear) : KS(d / 16), n_act(n_linear - 1) {}
-  __host__ __device__ size_t chunk_bytes() const { return ((size_t)SUNERF_KS0 + (size_t)n_act * 2 * KS) * 1024; }
-  __host__ __device__ size_t h_off(int l) const { return ((size_t)SUNERF_KS0 + (size_t)l * 2 * KS) * 1024; }
-  __host__ __device__ size_t c_off(int l) const { return h_off(l) + (size_t)KS * 1024; }
+  bool phase;
+  __host__ __device__ StashLayout(int d, int n_linear, bool phase_format = false) : KS(d / 16), n_act(n_linear - 1), phase(phase_format) {}
+  __host__ __device__ size_t layer_bytes() const { return (size_t)(phase ? 1 : 2) * KS * 1024; }
+  __host__ __device__ size_t chunk_bytes() const { return (size_t)SUNERF_KS0 * 1024 + (size_t)n_act * layer_bytes(); }
+  // first fragment of layer l's block: H_l (FP16 format) / P_l (PHASE format)
+  __host__ __device__ size_t h_off(int l) const { return (size_t)SUNERF_KS0 * 1024 + (size_t)l * layer_bytes(); }
+  __host__ __device__ size_t c_off(int l) const { return h_off(l) + (size_t)KS * 1024; }      // FP16 format only
 };
+constexpr float SUNERF_PHASE_SCALE = 1.f / 65535.f;      // phase code -> revolutions
 
 // input feature (column of the nn.Linear weight) held by (k-step s, lane half h, element e); -1 = zero pad
 __host__ __device__ inline int kmap_hidden(int s, int h, int e) {

@@ -27,11 +27,11 @@ _SIGNATURES = {
                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void, c_void]),
     'sunerf_sample_z': (ctypes.c_int, [ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int64, ctypes.c_int,
                                         ctypes.c_float, ctypes.c_float, c_f32p, c_void]),
-    'sunerf_act_stash_bytes': (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    'sunerf_act_stash_bytes': (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     'sunerf_render_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int]),
     'sunerf_emission_render_fwd': (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p,
                                                    ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p,
-                                                   c_f32p, c_f32p, c_f32p, ctypes.c_float, c_void, c_void, ctypes.c_size_t,
+                                                   c_f32p, c_f32p, c_f32p, ctypes.c_float, c_void, ctypes.c_int, c_void, ctypes.c_size_t,
                                                    c_void]),
     'sunerf_packed_mlp_t_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     'sunerf_pack_mlp_t': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -71,7 +71,7 @@ _SIGNATURES = {
     'sunerf_hier_resample': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                              ctypes.c_int, c_f32p, c_f32p, c_void]),
     'sunerf_mlp_points_fwd': (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_int64, c_f32p,
-                                              c_void, c_void, ctypes.c_size_t, c_void]),
+                                              c_void, ctypes.c_int, c_void, ctypes.c_size_t, c_void]),
     'sunerf_sample_pdf': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                           c_f32p, c_void]),
     'sunerf_observer_rays': (ctypes.c_int, [c_void, c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
@@ -110,7 +110,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.sunerf_abi_version() != 8:
+        if lib.sunerf_abi_version() != 9:
             raise SunerfHipError('libsunerf_hip.so ABI version mismatch')
         _lib = lib
     return _lib

@@ -68,6 +68,39 @@ def default_precision(d_filter: int) -> int:
 
 
 _workspaces = {}                        # (device, stream) -> scratch of the d_filter = 512 render kernel
+STASH_FP16, STASH_PHASE = 0, 1          # include/sunerf_hip.h: SUNERF_STASH_*
+
+
+def training_stash_format(packed, n_rays: int, n_samples: int) -> int:
+    """What the training forward leaves for the backward: 16-bit phases (half the bytes; what the layer-pipelined backward reads)
+    whenever that backward is going to run -- d_filter 256 on a 256-CU device, SUNERF_BACKWARD not 'classic', no rank sharing the
+    card --, fp16 sin + cos fragments for the two-kernel backward otherwise.  ``SUNERF_STASH=fp16`` forces the latter (and with
+    it the two-kernel backward)."""
+    if os.environ.get('SUNERF_STASH', '').strip().lower() == 'fp16' or n_rays <= 0:
+        return STASH_FP16
+    if backward_mode() != 'pipe':
+        return STASH_FP16
+    with torch.cuda.device(packed.device):
+        ok = _l.load().sunerf_bwd_pipe_workspace_bytes(n_rays, n_samples, packed.d_filter, packed.n_linear) > 0
+    if not ok or _shared_device(packed.device):
+        return STASH_FP16
+    return STASH_PHASE
+
+
+def stash_format_of(stash, n_rays: int, n_samples: int, packed) -> int:
+    """The format a stash tensor was written in, told by its size (the two formats differ by almost 2 x): the size of this batch
+    exactly, or -- a stash of more rays used for its first ``n_rays`` (both formats are ray-major) -- a whole number of chunks of
+    one format only."""
+    lib = _l.load()
+    need = {fmt: lib.sunerf_act_stash_bytes(n_rays, n_samples, packed.d_filter, packed.n_linear, fmt) for fmt in (STASH_PHASE, STASH_FP16)}
+    for fmt, nbytes in need.items():
+        if nbytes and stash.numel() == nbytes:
+            return fmt
+    chunk = {fmt: lib.sunerf_act_stash_bytes(1, 1, packed.d_filter, packed.n_linear, fmt) // 2 for fmt in need}     # (1 chunk + 1 spare)
+    fits = [fmt for fmt, nbytes in need.items() if nbytes and stash.numel() > nbytes and stash.numel() % chunk[fmt] == 0]
+    if len(fits) == 1:
+        return fits[0]
+    raise ValueError('the activation stash does not have the size of either format for this batch')
 
 
 def _dev(t: torch.Tensor, name: str, shape=None) -> torch.Tensor:
@@ -336,9 +369,10 @@ def emission_render_fwd(packed: PackedMLP, rays_o, rays_d, times, z_vals, reg_ra
         if ws is None or ws.numel() < ws_bytes:
             ws = _workspaces[key] = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     raw = torch.empty(n, s, 2, **f32) if want_raw else None
-    stash = None
+    stash, fmt = None, STASH_FP16
     if training:
-        stash = torch.empty(lib.sunerf_act_stash_bytes(n, s, packed.d_filter, packed.n_linear), dtype=torch.uint8,
+        fmt = training_stash_format(packed, n, s)
+        stash = torch.empty(lib.sunerf_act_stash_bytes(n, s, packed.d_filter, packed.n_linear, fmt), dtype=torch.uint8,
                             device=dev)
     hm = am = reg = None
     if want_epilogues:
@@ -346,7 +380,7 @@ def emission_render_fwd(packed: PackedMLP, rays_o, rays_d, times, z_vals, reg_ra
     _l.call(dev, 'sunerf_emission_render_fwd', _ptr(weights_image), packed.d_filter, packed.n_linear,
             precision, _ptr(rays_o), _ptr(rays_d), _ptr(times), _ptr(z_vals), n, s, _ptr(out['image']),
             _ptr(out['weights']), _ptr(out['absorption']), _ptr(raw), _ptr(hm), _ptr(am), _ptr(reg),
-            float(reg_radius), _ptr(stash), _ptr(ws), ws_bytes, _stream(dev))
+            float(reg_radius), _ptr(stash), fmt, _ptr(ws), ws_bytes, _stream(dev))
     if want_raw:
         out['raw'] = raw
     if training:
@@ -389,11 +423,12 @@ def mlp_points_fwd(packed: PackedMLP, points: torch.Tensor, training: bool = Fal
         if ws is None or ws.numel() < ws_bytes:
             ws = _workspaces[key] = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     raw = torch.empty(m_pad, 2, dtype=torch.float32, device=dev)
-    stash = None
+    stash, fmt = None, STASH_FP16
     if training:
-        stash = torch.empty(lib.sunerf_act_stash_bytes(m_pad // 32, 32, packed.d_filter, packed.n_linear), dtype=torch.uint8, device=dev)
+        fmt = training_stash_format(packed, m_pad // 32, 32)
+        stash = torch.empty(lib.sunerf_act_stash_bytes(m_pad // 32, 32, packed.d_filter, packed.n_linear, fmt), dtype=torch.uint8, device=dev)
     _l.call(dev, 'sunerf_mlp_points_fwd', _ptr(weights_image), packed.d_filter, packed.n_linear, precision, _ptr(points),
-            m_pad, _ptr(raw), _ptr(stash), _ptr(ws), ws_bytes, _stream(dev))
+            m_pad, _ptr(raw), _ptr(stash), fmt, _ptr(ws), ws_bytes, _stream(dev))
     out = {'raw': raw[:m], 'n_padded': m_pad}
     if training:
         out['stash'] = stash
@@ -742,11 +777,19 @@ def mlp_backward(packed: PackedMLP, g_raw, absmax, stash, grad_weights: Sequence
     stream = _stream(dev)
     exact = _use_exact_backward(n * s, query)
     pipe_bytes = 0
-    if n > 0 and not exact and backward_mode() == 'pipe':
-        with torch.cuda.device(dev):
-            pipe_bytes = lib.sunerf_bwd_pipe_workspace_bytes(n, s, D, nl)     # 0: shape / device outside the pipelined kernel
-        if pipe_bytes and _shared_device(dev):
-            pipe_bytes = 0
+    if n > 0 and not exact:
+        # the forward chose the stash format for the backward it expected (training_stash_format): phases are read by the
+        # pipelined kernel only, fp16 sin + cos fragments by the two kernels only
+        fmt = stash_format_of(stash, n, s, packed)
+        if fmt == STASH_PHASE:
+            if backward_mode() != 'pipe':
+                raise _l.SunerfHipError('this activation stash holds 16-bit phases (written for the layer-pipelined backward) but the '
+                                        'two-kernel backward was selected after the forward ran: choose SUNERF_BACKWARD before the forward, '
+                                        'or SUNERF_STASH=fp16')
+            with torch.cuda.device(dev):
+                pipe_bytes = lib.sunerf_bwd_pipe_workspace_bytes(n, s, D, nl)
+            if not pipe_bytes:
+                raise _l.SunerfHipError('phase stash but no pipelined backward for this shape / device')
     if not pipe_bytes and not exact:
         dz = torch.empty(lib.sunerf_dz_stash_bytes(n, s, D, nl), dtype=torch.uint8, device=dev)
         _l.call(dev, 'sunerf_mlp_dgrad', _ptr(packed.transposed()), D, nl, _ptr(g_raw), _ptr(absmax), _ptr(stash),

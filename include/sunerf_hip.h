@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SUNERF_ABI_VERSION 8
+#define SUNERF_ABI_VERSION 9
 
 #define SUNERF_E_BADARG   (-1)   /* null pointer / non-positive size                               */
 #define SUNERF_E_UNSUPPORTED (-2) /* d_filter / n_layers / sample count outside the compiled set     */
@@ -103,9 +103,14 @@ int sunerf_sample_z(int sampler_kind, const float* rays_o, const float* rays_d, 
  *   reg_radius : 1.2 / Rs_per_ds (base_tracing.py:44)
  *   act_stash  : NULL for inference; for training a device buffer of sunerf_act_stash_bytes() bytes that
  *                receives the hidden activations for the backward kernels
+ *   stash_format: SUNERF_STASH_FP16 -- fp16 sin and fp16 cos of every activation (8.2 KB per sample of an 8 x 256 network): what
+ *                sunerf_mlp_dgrad / sunerf_mlp_wgrad read -- or SUNERF_STASH_PHASE -- the 16-bit phase of every pre-activation
+ *                (4.1 KB per sample; sin and cos to 4.8e-5 from it): what sunerf_mlp_backward_pipe reads; d_filter = 256 only
  *   workspace  : sunerf_render_workspace_bytes(d_filter) bytes of device scratch (may be NULL when that is 0)
  * ---------------------------------------------------------------------------------------------------------- */
-size_t sunerf_act_stash_bytes(int64_t n_rays, int n_samples, int d_filter, int n_linear);
+#define SUNERF_STASH_FP16  0
+#define SUNERF_STASH_PHASE 1
+size_t sunerf_act_stash_bytes(int64_t n_rays, int n_samples, int d_filter, int n_linear, int stash_format);
 /* d_filter = 512 (the reference's default width, model.py:16): scratch for layer outputs; 0 for narrower nets */
 size_t sunerf_render_workspace_bytes(int d_filter);
 
@@ -114,8 +119,8 @@ int sunerf_emission_render_fwd(const void* packed, int d_filter, int n_linear, i
                                const float* z_vals, int64_t n_rays, int n_samples,
                                float* image, float* weights, float* absorption, float* raw,
                                float* height_map, float* absorption_map, float* regularization,
-                               float reg_radius, void* act_stash, void* workspace, size_t workspace_bytes,
-                               void* stream);
+                               float reg_radius, void* act_stash, int stash_format, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* NeRF.forward on free-standing query points, model.py:44-57 (positional encoding + sine MLP, no ray, no integral): the fused
  * render kernel fed with explicit points.  points [M,4] = (x, y, z, t), M a multiple of 32 (callers pad); raw [M,2].
@@ -123,7 +128,7 @@ int sunerf_emission_render_fwd(const void* packed, int d_filter, int n_linear, i
  * sunerf_mlp_wgrad then take g_raw [M/32, 32, 2] (a loss on arbitrary points trains, as the reference's module call does).
  * Serves evaluation/loader.py:load_coords (volume queries) at the kernel's full rate. */
 int sunerf_mlp_points_fwd(const void* packed, int d_filter, int n_linear, int precision, const float* points,
-                          int64_t n_points, float* raw, void* act_stash, void* workspace, size_t workspace_bytes,
+                          int64_t n_points, float* raw, void* act_stash, int stash_format, void* workspace, size_t workspace_bytes,
                           void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -182,6 +187,8 @@ int sunerf_mlp_wgrad(int d_filter, int n_linear, int d_out, const void* packedT,
  * sunerf/model/model.py:44-57.  A streaming prologue forms dZ of the last activation layer and the out layer's dW / db; then
  * one persistent launch in which pairs of workgroups own one Linear layer each (its dW accumulators and W^T rows stay in
  * registers) and hand dZ from layer to layer through the L2 of the XCD they share.
+ *   act_stash: written by the forward with stash_format = SUNERF_STASH_PHASE [ABI 9] (the 16-bit phase of every pre-activation:
+ *              half the bytes of the fp16 sin + cos stash the two-kernel backward reads; decoded inside the kernel)
  *   workspace: sunerf_bwd_pipe_workspace_bytes(...) bytes (0 = configuration not supported: use dgrad + wgrad).  Its first 256
  *              bytes (SUNERF_PIPE_WS_STICKY) are a STICKY STATUS block that belongs to the caller: zero it once after the
  *              allocation; word 0 is only ever raised by the library, to the largest launch status seen: 0 = every launch since

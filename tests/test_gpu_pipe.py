@@ -54,10 +54,10 @@ def _hip_grads(ops, mode, params, o, d, t, z, g_image, g_reg_const, reps=1, monk
     dev = torch.device('cuda')
     Ws, bs = [W.to(dev) for W, _ in params], [b.to(dev) for _, b in params]
     packed = ops.PackedMLP(Ws, bs, precision=ops.PRECISION_EXACT)
-    fwd = ops.emission_render_fwd(packed, o.to(dev), d.to(dev), t.to(dev), z.to(dev), reg_radius=1.2, training=True)
     prev = ops._backward_forced
-    ops._backward_forced = mode
+    ops._backward_forced = mode          # (before the forward: it leaves the stash in the format this backward reads)
     try:
+        fwd = ops.emission_render_fwd(packed, o.to(dev), d.to(dev), t.to(dev), z.to(dev), reg_radius=1.2, training=True)
         for _ in range(reps):
             gW = [torch.full_like(W, float('nan')) for W in Ws]
             gb = [torch.full_like(b, float('nan')) for b in bs]
@@ -86,10 +86,11 @@ def test_pipelined_backward_matches_oracle_and_two_kernel_backward(ops, n_side, 
             e_cls = ((p - c).norm() / c.norm()).item()
             worst_ref, worst_classic = max(worst_ref, e_ref), max(worst_classic, e_cls)
             assert e_ref < 1e-3, (i, name, 'vs oracle', e_ref)
-            # weights: same operands, same products (fp16 heads + remainders of W^T, fp16 H / cos / dZ), only the order of the fp32
-            # sums differs.  Biases: the pipelined backward sums dH * cos in fp32 BEFORE its rounding to fp16 (round 4), the two-kernel
-            # one sums the rounded dZ: they differ by that rounding's share, 2^-12 / sqrt(samples) x the sum's conditioning
-            assert e_cls < (2e-5 if name == 'weight' else 3e-4), (i, name, 'vs two-kernel backward', e_cls)
+            # Until round 4 both backwards multiplied the same operands and differed by summation order only (2e-5).  Now the
+            # pipelined one reads the 16-bit PHASE stash (sin and cos decoded to 4.8e-5 absolute, cos kept in fp32) and sums db in
+            # fp32 before dZ is rounded, the two-kernel one reads fp16 sin / cos fragments: two fp16-class evaluations of the same
+            # gradient, each within 1e-3 of the oracle, a few 1e-4 apart
+            assert e_cls < 1e-3, (i, name, 'vs two-kernel backward', e_cls)
     print(f'{o.shape[0]} rays x {S}, {n_layers} layers: pipelined vs oracle {worst_ref:.2e}, vs two-kernel {worst_classic:.2e}')
 
 
@@ -142,7 +143,7 @@ def test_training_batch_through_pipelined_backward(ops):
     pipe, status = _hip_grads(ops, 'pipe', params, o, d, t, z, g_image, 2e-5)
     assert status == 0
     for (cW, cb), (pW, pb) in zip(classic, pipe):
-        assert ((pW - cW).norm() / cW.norm()).item() < 5e-5 and ((pb - cb).norm() / cb.norm()).item() < 3e-4   # (biases: fp32 sums here)
+        assert ((pW - cW).norm() / cW.norm()).item() < 6e-4 and ((pb - cb).norm() / cb.norm()).item() < 6e-4   # (two fp16-class evaluations)
 
 
 def test_a_launch_that_gives_up_leaves_nan_gradients_and_the_process_falls_back(ops, monkeypatch):
@@ -161,9 +162,9 @@ def test_a_launch_that_gives_up_leaves_nan_gradients_and_the_process_falls_back(
     dev = torch.device('cuda')
     Ws, bs = [W.to(dev) for W, _ in params], [b.to(dev) for _, b in params]
     packed = ops.PackedMLP(Ws, bs, precision=ops.PRECISION_EXACT)
-    fwd = ops.emission_render_fwd(packed, o.to(dev), d.to(dev), t.to(dev), z.to(dev), reg_radius=1.2, training=True)
 
-    def backward():
+    def backward():       # forward + backward, like a training step: the forward writes the stash in the format of the backward in force
+        fwd = ops.emission_render_fwd(packed, o.to(dev), d.to(dev), t.to(dev), z.to(dev), reg_radius=1.2, training=True)
         gW = [torch.zeros_like(W) for W in Ws]
         gb = [torch.zeros_like(b) for b in bs]
         ops.emission_render_bwd(packed, o.to(dev), d.to(dev), z.to(dev), fwd['raw'], fwd['stash'], g_image.to(dev), None, 2e-5, 1.2, gW, gb)

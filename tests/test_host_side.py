@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(sunerf_hip.EXPORTED_SYMBOLS), declared ^ set(sunerf_hip.EXPORTED_SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.sunerf_abi_version() == 8
+    assert lib.sunerf_abi_version() == 9
 
 
 def test_size_helpers(lib):
@@ -38,8 +38,11 @@ def test_size_helpers(lib):
     # out^T hi only; hidden hi + lo; + the 16 per-layer sums of squares the backward boosts are chosen from
     assert lib.sunerf_packed_mlp_t_bytes(256, 9) == 8 * 1024 + 7 * 8 * 16 * 2048 + 16 * 4
     # stash: (6 enc + 8 layers x 2 x 16) fragments of 1 KiB per 32-sample chunk, + 1 spare chunk
-    assert lib.sunerf_act_stash_bytes(10, 128, 256, 9) == (10 * 4 + 1) * (6 + 8 * 32) * 1024
-    assert lib.sunerf_act_stash_bytes(10, 130, 256, 9) == (10 * 5 + 1) * (6 + 8 * 32) * 1024      # ragged last chunk
+    assert lib.sunerf_act_stash_bytes(10, 128, 256, 9, 0) == (10 * 4 + 1) * (6 + 8 * 32) * 1024
+    assert lib.sunerf_act_stash_bytes(10, 130, 256, 9, 0) == (10 * 5 + 1) * (6 + 8 * 32) * 1024      # ragged last chunk
+    # 16-bit phase format (what the pipelined backward reads): one fragment set per layer instead of sin + cos; d_filter 256 only
+    assert lib.sunerf_act_stash_bytes(10, 128, 256, 9, 1) == (10 * 4 + 1) * (6 + 8 * 16) * 1024
+    assert lib.sunerf_act_stash_bytes(10, 128, 128, 9, 1) == 0 and lib.sunerf_act_stash_bytes(10, 128, 256, 9, 2) == 0
     assert lib.sunerf_dz_stash_bytes(10, 128, 256, 9) == (10 * 4 + 1) * 8 * 16 * 1024
     assert lib.sunerf_wgrad_workspace_bytes(256, 9, 32) == 9 * 32 * 72 * 1024 * 4   # 8 x (8 + bias column) tiles
     assert lib.sunerf_wgrad_workspace_bytes(512, 9, 7) == 9 * 7 * 16 * 17 * 1024 * 4
@@ -52,12 +55,12 @@ def test_argument_errors_without_gpu(lib):
     assert lib.sunerf_sample_z(7, None, None, None, None, 0, 8, 1.3, 1.0, None, None) == -2      # unknown sampler kind
     assert lib.sunerf_hier_resample(None, None, None, 0, 4, 8, 8, None, None, None) == -1
     assert lib.sunerf_emission_render_fwd(None, 256, 9, 0, None, None, None, None, 4, 8, None, None, None, None, None, None,
-                                          None, 1.2, None, None, 0, None) == -1
+                                          None, 1.2, None, 0, None, 0, None) == -1
     # precision: an unknown mode is a bad argument
     assert lib.sunerf_emission_render_fwd(None, 256, 9, 5, None, None, None, None, 4, 8, None, None, None, None, None, None,
-                                          None, 1.2, None, None, 0, None) == -1
+                                          None, 1.2, None, 0, None, 0, None) == -1
     assert lib.sunerf_emission_render_fwd(None, 384, 9, 0, None, None, None, None, 4, 8, None, None, None, None, None, None,
-                                          None, 1.2, None, None, 0, None) == -1        # null pointers are checked first
+                                          None, 1.2, None, 0, None, 0, None) == -1        # null pointers are checked first
     assert lib.sunerf_render_workspace_bytes(256) == 0 and lib.sunerf_render_workspace_bytes(512) == 1024 * 4 * 32 * 2048
 
 

@@ -25,11 +25,11 @@ def run(n_side, S, reps, d_filter=256, n_layers=8):
     bs = [b.to(dev) for _, b in params]
     packed = ops.PackedMLP(Ws, bs)
     o, d, t, z = o.to(dev), d.to(dev), t.to(dev), z.to(dev)
-    fwd = ops.emission_render_fwd(packed, o, d, t, z, reg_radius=1.2, training=True)
     g_image = torch.randn(n, device=dev) * 1e-3
     res = {}
     for mode in ('classic', 'pipe'):
         ops._backward_forced = mode
+        fwd = ops.emission_render_fwd(packed, o, d, t, z, reg_radius=1.2, training=True)      # (stash in the format this backward reads)
         gW = [torch.full_like(W, float('nan')) for W in Ws]
         gb = [torch.full_like(b, float('nan')) for b in bs]
         ops.emission_render_bwd(packed, o, d, z, fwd['raw'], fwd['stash'], g_image, None, 2e-5, 1.2, gW, gb)
