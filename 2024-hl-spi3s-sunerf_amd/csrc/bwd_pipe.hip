@@ -45,7 +45,13 @@ constexpr int WG_PRE = 256;             // prologue kernel
 constexpr int NBUF = 4;                 // staging buffers of the in-layer stage and of the prologue (chunks in flight: NBUF - 1)
 constexpr int NBUF_H = 5;               // ... of a hidden stage: chunk it + 4 is being fetched, chunk it + 1's phases are decoded, chunk it is consumed
 constexpr int DRAIN = 4;                // a wave's output stores of chunk c have left it by its counted wait of iteration c + DRAIN
-constexpr int RING = 16;                // chunk slots per hand-off ring
+#ifndef PIPE_RING
+#define PIPE_RING 16
+#endif
+#ifndef PIPE_POLL_LAG
+#define PIPE_POLL_LAG 2                 // iterations between the issue of a counter poll and the gate that reads it (1 .. NBUF_H - 1); 4 -> 2: kernel 12.2 -> 11.8 ms (r4_pipe_ab7)
+#endif
+constexpr int RING = PIPE_RING;                // chunk slots per hand-off ring
 constexpr int SLOT = PKS * 1024;        // one chunk of dZ: 16 fragments
 constexpr int BUF_HID = 24 * 1024;      // hidden stage staging: dZ_l 16 | P[J] 8 KiB (16-bit phases, decoded IN PLACE to fp16 sin = H[J])
 constexpr int BUF_IN = 16 * 1024;       // in-layer stage staging: dZ_0[J] 8 | enc 6 (| 2 unused) KiB
@@ -336,7 +342,19 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       dp[0] = *(const lds_v4u*)(uintptr_t)at;
       dp[1] = *(const lds_v4u*)(uintptr_t)(at + 1024);
     };
+#ifndef PIPE_SPLIT_DECODE
+#define PIPE_SPLIT_DECODE 0      // experiment (r4_pipe_ab6): 1 = these waves form the cosines only, the weight-gradient waves 5 - 7 the sines right behind the barrier; measured 12.44 against 12.26 ms -- the weight waves became the long ones (24 sines cost them 1700 clocks beside the data waves' matrix instructions)
+#endif
     auto decode = [&](int b) __attribute__((always_inline)) {
+      if (PIPE_SPLIT_DECODE) {
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const unsigned w = dp[e >> 3][(e & 7) >> 1];
+          cosn[e] = __builtin_amdgcn_cosf((float)(w & 0xffffu) * SUNERF_PHASE_SCALE);
+          cosn[e + 1] = __builtin_amdgcn_cosf((float)(w >> 16) * SUNERF_PHASE_SCALE);
+        }
+        return;
+      }
       const unsigned at = lds0 + b * BUF_HID + (16 + 2 * wave) * 1024 + voff;
       float sn[16];
       decode_phases(dp[0], sn, cosn);
@@ -349,6 +367,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     bool stop = false;
     for (int it = -(NBUF_H - 1); it < 0; ++it) {
       asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NO + 2 * (NP_D + NO)) : "memory");
+      if (PIPE_SPLIT_DECODE && it == -1 && n_my > 0) read_phases(0);      // (in front of the barrier: the sines overwrite them behind it)
       barrier_mem();
       const unsigned ab = lds_ld(lds_abort + (it & 1) * 4);
       next_chunk(it + NBUF_H - 1);
@@ -359,7 +378,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       buf_store(zero, sc, 0);
       buf_store(zero, sc, 1024);
       if (ab) { stop = true; break; }
-      if (it == -1 && n_my > 0) { read_phases(0); decode(0); }
+      if (it == -1 && n_my > 0) { if (!PIPE_SPLIT_DECODE) read_phases(0); decode(0); }
     }
     unsigned long long ph[4] = {0, 0, 0, 0};      // SUNERF_PIPE_DEBUG: shader clocks in wait / barrier / k-steps / epilogue + decode
     unsigned long long tl[5] = {0, 0, 0, 0, 0};   //   and the stamps of iteration n_my / 2 themselves
@@ -379,6 +398,9 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NO + 2 * (NP_D + NO)) : "memory");
       const int nbuf = buf + 1 == NBUF_H ? 0 : buf + 1;
       const bool decode_next = it + 1 < n_my;
+      // split decoding: the next chunk's phases (this wave's own pieces: landed by the wait above) are read HERE, in front of the
+      // barrier behind which the weight-gradient waves overwrite them with their sines
+      if (PIPE_SPLIT_DECODE && decode_next) read_phases(nbuf);
       if (stamp) s1 = __builtin_amdgcn_s_memtime();
       barrier_mem();
       if (stamp) s2 = __builtin_amdgcn_s_memtime();
@@ -405,7 +427,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
         if (ks == 6) piece_z(12 + wave);
         if (!PIPE_PHASE_ON_WEIGHT && ks == 8) piece_p(2 * wave);
         if (!PIPE_PHASE_ON_WEIGHT && ks == 10) piece_p(2 * wave + 1);
-        if (ks == 12 && decode_next) read_phases(nbuf);      // the next chunk's phases, decoded behind the epilogue
+        if (!PIPE_SPLIT_DECODE && ks == 12 && decode_next) read_phases(nbuf);      // the next chunk's phases, decoded behind the epilogue
         __builtin_amdgcn_sched_barrier(0);
       }
       if (stamp) { asm volatile("" :: "v"(dacc)); s3 = __builtin_amdgcn_s_memtime(); }
@@ -508,7 +530,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   unsigned long long tw = 0, tb = 0;       // SUNERF_PIPE_DEBUG: shader clocks in the counted wait / the barrier
   unsigned long long t_wait = 0, t_bar = 0, tl[6] = {0, 0, 0, 0, 0, 0};
   const bool stamp = a.dbg != nullptr;
-  int pslot = NBUF_H - 1;                  // (it + NBUF_H - 1) % NBUF_H: LDS slot of the poll issued in iteration `it`
+  int pslot = PIPE_POLL_LAG;               // the poll issued in iteration `it` lands in LDS slot (it + PIPE_POLL_LAG) % NBUF_H, read in iteration it + PIPE_POLL_LAG
   auto top = [&](int it) __attribute__((always_inline)) {
     unsigned long long sa = 0, sb = 0;
     if (stamp) sa = __builtin_amdgcn_s_memtime();
@@ -516,7 +538,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     if (gatew) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * 4) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * 2) : "memory");
 #else
-    if (gatew) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * 2) : "memory");      // (the poll issued NBUF_H-1 iterations ago has landed)
+    if (gatew) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PIPE_POLL_LAG >= 3 ? 2 * 2 : 2 * (PIPE_POLL_LAG - 1)) : "memory");      // (the poll issued PIPE_POLL_LAG iterations ago has landed)
 #endif
     if (stamp) sb = __builtin_amdgcn_s_memtime();
     barrier_mem();
@@ -536,9 +558,35 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     }
     return ab;
   };
-  for (int it = -(NBUF_H - 1); it < 0; ++it) {      // prologue iterations: protocol only
+  // Split decoding: fp16 sin of the phase fragments of the chunk in staging buffer `b`, IN PLACE -- the image this stage's transposed
+  // H reads take one iteration later.  Waves 5, 6, 7 take 3, 3, 2 of the eight fragments (wave 4 has the protocol); called right
+  // behind the barrier, i.e. while the data-gradient wave of the same SIMD issues its matrix instructions and leaves the vector
+  // pipe alone (behind these waves' own matrix instructions, beside the data wave's epilogue, the same work took 900 clocks).
+  // Every data wave has fetched and read its two fragments in front of that barrier.
+  auto decode_sin = [&](int b) __attribute__((always_inline)) {
+    if (!PIPE_SPLIT_DECODE || gatew) return;
+    typedef __attribute__((address_space(3))) v4u lds_v4u_;
+    typedef __attribute__((address_space(3))) half8 lds_half8_;
+    const int f0 = 3 * (v - 1), nf = v == 3 ? 2 : 3;
+    const unsigned at = lds0 + b * BUF_HID + (16 + f0) * 1024 + lane * 16;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      if (f < nf) {
+        const v4u p = *(const lds_v4u_*)(uintptr_t)(at + f * 1024);
+        half8 hs;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          hs[2 * q] = (_Float16)__builtin_amdgcn_sinf((float)(p[q] & 0xffffu) * SUNERF_PHASE_SCALE);
+          hs[2 * q + 1] = (_Float16)__builtin_amdgcn_sinf((float)(p[q] >> 16) * SUNERF_PHASE_SCALE);
+        }
+        *(lds_half8_*)(uintptr_t)(at + f * 1024) = hs;
+      }
+    }
+  };
+  for (int it = -(NBUF_H - 1); it < 0; ++it) {      // prologue iterations: protocol only (split decoding: + the sines of chunk 0)
     const unsigned ab = top(it);
     if (PIPE_PHASE_ON_WEIGHT) { piece_p(2 * v); piece_p(2 * v + 1); }
+    if (it == -1 && n_my > 0) decode_sin(0);
     if (ab) { aborted = true; break; }
     if (gatew && it + 1 < n_my) gate(it + 1);
   }
@@ -549,6 +597,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     unsigned long long s0 = 0, s1 = 0, s2 = 0;
     if (stamp) s0 = __builtin_amdgcn_s_memtime();
     const unsigned ab = top(it);
+    if (it + 1 < n_my) decode_sin(buf + 1 == NBUF_H ? 0 : buf + 1);      // the NEXT chunk's sines
     if (stamp) s1 = __builtin_amdgcn_s_memtime();
     // operand bases of this wave's block: row tiles r0.. of the dZ fragments, column tiles c0.. of the H fragments (fp16 sin,
     // decoded in place by the data-gradient waves one iteration ago); the tile and k-step parts of the addresses are immediates
