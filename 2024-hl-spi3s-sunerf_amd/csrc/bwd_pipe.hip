@@ -44,7 +44,9 @@ constexpr int WG = 512;                 // pipelined kernel: eight waves, two pe
 constexpr int WG_PRE = 256;             // prologue kernel
 constexpr int NBUF = 4;                 // staging buffers of the in-layer stage and of the prologue (chunks in flight: NBUF - 1)
 constexpr int NBUF_H = 5;               // ... of a hidden stage: chunk it + 4 is being fetched, chunk it + 1's phases are decoded, chunk it is consumed
-constexpr int DRAIN = 4;                // a wave's output stores of chunk c have left it by its counted wait of iteration c + DRAIN
+#ifndef PIPE_ZD
+#define PIPE_ZD 2                       // hidden stages below the top: dZ_l is requested this many iterations before it is consumed
+#endif
 #ifndef PIPE_RING
 #define PIPE_RING 16
 #endif
@@ -263,24 +265,37 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   const char* srcP0 = a.act_stash + SL.h_off(l - 1) + (size_t)(8 * j) * 1024;
   const int64_t safe = cbeg < a.n_chunks_total ? cbeg : a.n_chunks_total - 1;     // a chunk inside the stashes for surplus DMA
 
-  // wave-uniform sources / LDS destination of the chunk being fetched (nxt = it + NBUF_H - 1), set at the top of an iteration
+  // Fetch distances.  The phases come from the stash -- nothing gates them -- and are wanted one iteration before their chunk is
+  // consumed: requested NBUF_H-1 iterations ahead.  dZ_l comes out of the hand-off ring: every iteration of distance is an
+  // iteration of lead the stage above must have, and one more before this stage's own outputs count as published (in-order
+  // vmcnt).  ZD = 2 iterations (~6000 clocks, an L2 read takes ~1000) leaves 9 of the ring's 16 slots as slack, 4 gave 6.
+  // The top stage reads dZ_top from HBM, ungated: it keeps the long distance.
+  constexpr int ZD = TOP ? NBUF_H - 1 : PIPE_ZD;
+  // wave-uniform sources / LDS destinations of the pieces being fetched, set at the top of an iteration: dZ of chunk it + ZD,
+  // phases of chunk it + NBUF_H - 1 (both into the staging buffer of their chunk, chunk % NBUF_H)
   const char *nz = nullptr, *np = nullptr;
-  unsigned ndst = 0;
-  bool nreal = false;
+  unsigned zdst = 0, pdst = 0;
+  bool zreal = false, preal = false;
   // (called with nxt = 0, 1, 2, ... in turn: the addresses advance by additions -- 64-bit multiplications here cost every wave
   // several hundred cycles per chunk)
   const char* const safe_p = srcP0 + (size_t)safe * act_chunk;
   const char* const safe_z = TOP ? a.dz_top + (size_t)safe * SLOT : ring_in;
   const char* run_p = srcP0 + (size_t)cbeg * act_chunk;
   const char* run_z = TOP ? a.dz_top + (size_t)cbeg * SLOT : ring_in;
-  int run_slot = 0, run_buf = 0;
-  auto next_chunk = [&](int nxt) __attribute__((always_inline)) {
-    nreal = nxt < n_my;
-    ndst = lds0 + run_buf * BUF_HID;
-    run_buf = run_buf + 1 == NBUF_H ? 0 : run_buf + 1;
-    nz = nreal ? run_z : safe_z;
-    np = nreal ? run_p : safe_p;
+  int run_slot = 0, run_zbuf = 0, run_pbuf = 0;
+  auto next_p = [&](int nxt) __attribute__((always_inline)) {
+    preal = nxt < n_my;
+    pdst = lds0 + run_pbuf * BUF_HID + 16 * 1024;
+    run_pbuf = run_pbuf + 1 == NBUF_H ? 0 : run_pbuf + 1;
+    np = preal ? run_p : safe_p;
     run_p += act_chunk;
+  };
+  auto next_z = [&](int nxt) __attribute__((always_inline)) {
+    if (nxt < 0) { zreal = false; nz = safe_z; return; }      // (prologue iterations ahead of chunk 0: surplus pieces)
+    zreal = nxt < n_my;
+    zdst = lds0 + run_zbuf * BUF_HID;
+    run_zbuf = run_zbuf + 1 == NBUF_H ? 0 : run_zbuf + 1;
+    nz = zreal ? run_z : safe_z;
     if (TOP) run_z += SLOT;
     else {
       run_slot = run_slot + 1 == RING ? 0 : run_slot + 1;
@@ -289,22 +304,27 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   };
   // LDS image of a chunk: pieces 0..15 dZ fragments, 16..23 P[J] (decoded in place to H[J])
   auto piece_z = [&](int f) __attribute__((always_inline)) {
-    const unsigned dst = nreal ? ndst + f * 1024 : lds_dummy;
+    const unsigned dst = zreal ? zdst + f * 1024 : lds_dummy;
     if (TOP) dma_piece_s<1>(nz + (size_t)f * 1024, voff, dst);
     else dma_piece_s<2>(nz + (size_t)f * 1024, voff, dst);
   };
-  auto piece_p = [&](int f) __attribute__((always_inline)) { dma_piece_s<1>(np + (size_t)f * 1024, voff, nreal ? ndst + (16 + f) * 1024 : lds_dummy); };
+  auto piece_p = [&](int f) __attribute__((always_inline)) { dma_piece_s<1>(np + (size_t)f * 1024, voff, preal ? pdst + f * 1024 : lds_dummy); };
+  // operations a data-gradient wave issues per iteration, in this order: 4 dZ pieces, 2 phase pieces, 2 output stores.  Its
+  // counted wait at the top of iteration `it` wants dZ of chunk `it` (issued in iteration it - ZD) and the phases of chunk it + 1
+  // (issued in it - 3): at most WAIT_LEFT younger operations outstanding.  The stores of iteration it - DRAIN come before all of
+  // those (vmcnt counts in issue order): chunk it - DRAIN of this stage's output is complete, which is what wave 4 publishes.
+  constexpr int NO = 2, NP_D = 6;
+  constexpr int WAIT_Z = (ZD - 1) * (NP_D + NO) + (NP_D - 4) + NO, WAIT_P = 2 * (NP_D + NO) + NO;
+  constexpr int WAIT_LEFT = WAIT_Z < WAIT_P ? WAIT_Z : WAIT_P;
+  constexpr int DRAIN = WAIT_LEFT >= WAIT_P ? 4 : ZD + 1;
+  static_assert(ZD >= 1 && ZD <= NBUF_H - 1, "dZ fetch distance");
 
   if (wave < 4) {
     // =============================================== data-gradient waves ===============================================
 #if defined(PIPE_PRIO) && PIPE_PRIO == 1
     __builtin_amdgcn_s_setprio(1);
 #endif
-#ifndef PIPE_PHASE_ON_WEIGHT
-#define PIPE_PHASE_ON_WEIGHT 0      // experiment: the phase pieces are fetched by the weight-gradient waves (two each, between their matrix instructions)
-#endif
     // output stores / DMA pieces (dZ fragments w, 4 + w, 8 + w, 12 + w; phase fragments 2 w, 2 w + 1 of this wave's own tile) per iteration
-    constexpr int NO = 2, NP_D = PIPE_PHASE_ON_WEIGHT ? 4 : 6;
 #ifndef PIPE_PF
 #define PIPE_PF 4
 #endif
@@ -342,19 +362,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       dp[0] = *(const lds_v4u*)(uintptr_t)at;
       dp[1] = *(const lds_v4u*)(uintptr_t)(at + 1024);
     };
-#ifndef PIPE_SPLIT_DECODE
-#define PIPE_SPLIT_DECODE 0      // experiment (r4_pipe_ab6): 1 = these waves form the cosines only, the weight-gradient waves 5 - 7 the sines right behind the barrier; measured 12.44 against 12.26 ms -- the weight waves became the long ones (24 sines cost them 1700 clocks beside the data waves' matrix instructions)
-#endif
     auto decode = [&](int b) __attribute__((always_inline)) {
-      if (PIPE_SPLIT_DECODE) {
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          const unsigned w = dp[e >> 3][(e & 7) >> 1];
-          cosn[e] = __builtin_amdgcn_cosf((float)(w & 0xffffu) * SUNERF_PHASE_SCALE);
-          cosn[e + 1] = __builtin_amdgcn_cosf((float)(w >> 16) * SUNERF_PHASE_SCALE);
-        }
-        return;
-      }
       const unsigned at = lds0 + b * BUF_HID + (16 + 2 * wave) * 1024 + voff;
       float sn[16];
       decode_phases(dp[0], sn, cosn);
@@ -366,19 +374,19 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     // last of them decodes chunk 0
     bool stop = false;
     for (int it = -(NBUF_H - 1); it < 0; ++it) {
-      asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NO + 2 * (NP_D + NO)) : "memory");
-      if (PIPE_SPLIT_DECODE && it == -1 && n_my > 0) read_phases(0);      // (in front of the barrier: the sines overwrite them behind it)
+      asm volatile("s_waitcnt vmcnt(%0)" :: "i"(WAIT_LEFT) : "memory");
       barrier_mem();
       const unsigned ab = lds_ld(lds_abort + (it & 1) * 4);
-      next_chunk(it + NBUF_H - 1);
+      next_z(it + ZD);
+      next_p(it + NBUF_H - 1);
       piece_z(wave); piece_z(4 + wave); piece_z(8 + wave); piece_z(12 + wave);
-      if (!PIPE_PHASE_ON_WEIGHT) { piece_p(2 * wave); piece_p(2 * wave + 1); }
+      piece_p(2 * wave); piece_p(2 * wave + 1);
       const Rsrc sc = make_rsrc(scratch, 2048);
       const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
       buf_store(zero, sc, 0);
       buf_store(zero, sc, 1024);
       if (ab) { stop = true; break; }
-      if (it == -1 && n_my > 0) { if (!PIPE_SPLIT_DECODE) read_phases(0); decode(0); }
+      if (it == -1 && n_my > 0) { read_phases(0); decode(0); }
     }
     unsigned long long ph[4] = {0, 0, 0, 0};      // SUNERF_PIPE_DEBUG: shader clocks in wait / barrier / k-steps / epilogue + decode
     unsigned long long tl[5] = {0, 0, 0, 0, 0};   //   and the stamps of iteration n_my / 2 themselves
@@ -391,23 +399,18 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     for (int it = 0; it < (stop ? 0 : n_my); ++it) {
       unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
       if (stamp) s0 = __builtin_amdgcn_s_memtime();
-      // The dZ pieces of chunk `it` (issued NBUF_H-1 iterations ago) and this wave's phase pieces of chunk it + 1 (issued NBUF_H-2
-      // ago) have landed once at most the two younger iterations' operations and the output stores issued behind those pieces
-      // are outstanding; the stores of chunk it - DRAIN, issued before them, are then complete as well (vmcnt counts in issue
-      // order) -- which is what wave 4 publishes
-      asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NO + 2 * (NP_D + NO)) : "memory");
+      // dZ of chunk `it` and this wave's phase pieces of chunk it + 1 have landed, the stores of chunk it - DRAIN are complete
+      asm volatile("s_waitcnt vmcnt(%0)" :: "i"(WAIT_LEFT) : "memory");
       const int nbuf = buf + 1 == NBUF_H ? 0 : buf + 1;
       const bool decode_next = it + 1 < n_my;
-      // split decoding: the next chunk's phases (this wave's own pieces: landed by the wait above) are read HERE, in front of the
-      // barrier behind which the weight-gradient waves overwrite them with their sines
-      if (PIPE_SPLIT_DECODE && decode_next) read_phases(nbuf);
       if (stamp) s1 = __builtin_amdgcn_s_memtime();
       barrier_mem();
       if (stamp) s2 = __builtin_amdgcn_s_memtime();
       // abort word of this iteration: requested now, looked at when the iteration's work is done (every wave leaves in the same
       // iteration, so the barrier counts still agree; what a doomed iteration computes and stores is garbage either way)
       const unsigned ab = lds_ld(lds_abort + (it & 1) * 4);
-      next_chunk(it + NBUF_H - 1);
+      next_z(it + ZD);
+      next_p(it + NBUF_H - 1);
       const char* B = smem + (size_t)buf * BUF_HID;
       f32x16 dacc = {0};
       half8 bf[PF + 1];
@@ -425,9 +428,9 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
         if (ks == 2) piece_z(4 + wave);
         if (ks == 4) piece_z(8 + wave);
         if (ks == 6) piece_z(12 + wave);
-        if (!PIPE_PHASE_ON_WEIGHT && ks == 8) piece_p(2 * wave);
-        if (!PIPE_PHASE_ON_WEIGHT && ks == 10) piece_p(2 * wave + 1);
-        if (!PIPE_SPLIT_DECODE && ks == 12 && decode_next) read_phases(nbuf);      // the next chunk's phases, decoded behind the epilogue
+        if (ks == 8) piece_p(2 * wave);
+        if (ks == 10) piece_p(2 * wave + 1);
+        if (ks == 12 && decode_next) read_phases(nbuf);      // the next chunk's phases, decoded behind the epilogue
         __builtin_amdgcn_sched_barrier(0);
       }
       if (stamp) { asm volatile("" :: "v"(dacc)); s3 = __builtin_amdgcn_s_memtime(); }
@@ -503,8 +506,8 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   // gate of iteration `itn` (wave 4): its DMA (chunk itn + NBUF_H - 1) needs that chunk published by both producers, its output
   // (slot itn % RING) needs chunk itn - RING landed in both consumers.  Normally the polled counters already say so.
   auto gate = [&](int itn) __attribute__((always_inline)) {
-    const int nx = itn + NBUF_H - 1;
-    const bool need_in = !TOP && nx < n_my && (int)(have_in - (unsigned)(nx + 1)) < 0;
+    const int nx = itn + ZD;      // (the chunk whose dZ the data waves request in iteration itn)
+    const bool need_in = !TOP && nx >= 0 && nx < n_my && (int)(have_in - (unsigned)(nx + 1)) < 0;
     const bool need_out = itn >= RING && (int)(have_out - (unsigned)(itn - RING + 1)) < 0;
     if (need_in || need_out) {
       bool ok = true;
@@ -534,17 +537,11 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   auto top = [&](int it) __attribute__((always_inline)) {
     unsigned long long sa = 0, sb = 0;
     if (stamp) sa = __builtin_amdgcn_s_memtime();
-#if PIPE_PHASE_ON_WEIGHT
-    if (gatew) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * 4) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * 2) : "memory");
-#else
     if (gatew) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PIPE_POLL_LAG >= 3 ? 2 * 2 : 2 * (PIPE_POLL_LAG - 1)) : "memory");      // (the poll issued PIPE_POLL_LAG iterations ago has landed)
-#endif
     if (stamp) sb = __builtin_amdgcn_s_memtime();
     barrier_mem();
     if (stamp) { t_wait = sb; t_bar = __builtin_amdgcn_s_memtime(); tw += sb - sa; tb += t_bar - sb; }
     const unsigned ab = lds_ld(lds_abort + (it & 1) * 4);     // looked at by the caller when the iteration's work is done
-    if (PIPE_PHASE_ON_WEIGHT) next_chunk(it + NBUF_H - 1);
     if (gatew) {
       // publish: chunk `it` has landed in this workgroup (its ring slot may be overwritten); the outputs of chunk
       // it - DRAIN are in L2 (the data waves' counted waits in front of the barrier).  One store instruction, lanes 0 and 1.
@@ -558,35 +555,8 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     }
     return ab;
   };
-  // Split decoding: fp16 sin of the phase fragments of the chunk in staging buffer `b`, IN PLACE -- the image this stage's transposed
-  // H reads take one iteration later.  Waves 5, 6, 7 take 3, 3, 2 of the eight fragments (wave 4 has the protocol); called right
-  // behind the barrier, i.e. while the data-gradient wave of the same SIMD issues its matrix instructions and leaves the vector
-  // pipe alone (behind these waves' own matrix instructions, beside the data wave's epilogue, the same work took 900 clocks).
-  // Every data wave has fetched and read its two fragments in front of that barrier.
-  auto decode_sin = [&](int b) __attribute__((always_inline)) {
-    if (!PIPE_SPLIT_DECODE || gatew) return;
-    typedef __attribute__((address_space(3))) v4u lds_v4u_;
-    typedef __attribute__((address_space(3))) half8 lds_half8_;
-    const int f0 = 3 * (v - 1), nf = v == 3 ? 2 : 3;
-    const unsigned at = lds0 + b * BUF_HID + (16 + f0) * 1024 + lane * 16;
-#pragma unroll
-    for (int f = 0; f < 3; ++f) {
-      if (f < nf) {
-        const v4u p = *(const lds_v4u_*)(uintptr_t)(at + f * 1024);
-        half8 hs;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          hs[2 * q] = (_Float16)__builtin_amdgcn_sinf((float)(p[q] & 0xffffu) * SUNERF_PHASE_SCALE);
-          hs[2 * q + 1] = (_Float16)__builtin_amdgcn_sinf((float)(p[q] >> 16) * SUNERF_PHASE_SCALE);
-        }
-        *(lds_half8_*)(uintptr_t)(at + f * 1024) = hs;
-      }
-    }
-  };
-  for (int it = -(NBUF_H - 1); it < 0; ++it) {      // prologue iterations: protocol only (split decoding: + the sines of chunk 0)
+  for (int it = -(NBUF_H - 1); it < 0; ++it) {      // prologue iterations: protocol only
     const unsigned ab = top(it);
-    if (PIPE_PHASE_ON_WEIGHT) { piece_p(2 * v); piece_p(2 * v + 1); }
-    if (it == -1 && n_my > 0) decode_sin(0);
     if (ab) { aborted = true; break; }
     if (gatew && it + 1 < n_my) gate(it + 1);
   }
@@ -597,7 +567,6 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     unsigned long long s0 = 0, s1 = 0, s2 = 0;
     if (stamp) s0 = __builtin_amdgcn_s_memtime();
     const unsigned ab = top(it);
-    if (it + 1 < n_my) decode_sin(buf + 1 == NBUF_H ? 0 : buf + 1);      // the NEXT chunk's sines
     if (stamp) s1 = __builtin_amdgcn_s_memtime();
     // operand bases of this wave's block: row tiles r0.. of the dZ fragments, column tiles c0.. of the H fragments (fp16 sin,
     // decoded in place by the data-gradient waves one iteration ago); the tile and k-step parts of the addresses are immediates
@@ -641,8 +610,6 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
         const half8 af = ks ? A1[i] : A0[i];
         mfma_agpr(acc[i][0], af, bf0);
         mfma_agpr(acc[i][1], af, bf1);
-        if (PIPE_PHASE_ON_WEIGHT && ks == 0 && i == 0) piece_p(2 * v);
-        if (PIPE_PHASE_ON_WEIGHT && ks == 0 && i == 2) piece_p(2 * v + 1);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
