@@ -167,6 +167,15 @@ __device__ __forceinline__ void dz_tile(const f32x16& acc, const float* c0, cons
     d1[j] = (_Float16)sunerf_sat16(p1);
   }
 }
+// ... one half of the tile: registers r0 .. r0 + 7
+__device__ __forceinline__ void dz_half(const f32x16& acc, int r0, const float* c, half8& d, float* bs) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float p = acc[r0 + j] * c[j];
+    bs[j] += p;
+    d[j] = (_Float16)sunerf_sat16(p);
+  }
+}
 // the 32 bias sums of a tile from the 16 x 64 per-lane sums: register g on lane half h is fragment-order index
 // 16 (g >> 3) + 8 h + (g & 7) of the tile (grad_common.h: reduce_grads_kernel reads bias slot `lane` as that index)
 __device__ __forceinline__ void store_bias_sums(const float* bs, float* dst32) {
@@ -314,9 +323,19 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   // (issued in it - 3): at most WAIT_LEFT younger operations outstanding.  The stores of iteration it - DRAIN come before all of
   // those (vmcnt counts in issue order): chunk it - DRAIN of this stage's output is complete, which is what wave 4 publishes.
   constexpr int NO = 2, NP_D = 6;
+#ifndef PIPE_PIECES_LATE
+#define PIPE_PIECES_LATE 0      // experiment (r4_pipe_ab10): 1 = the six pieces between the vector work behind the k-steps; 11.60 against 11.45 ms
+#endif
+#if PIPE_PIECES_LATE
+  // (pieces issued between the vector work behind the k-steps, in the order z z s s z z p p)
+  constexpr int WAIT_Z = (ZD - 1) * (NP_D + NO) + 2, WAIT_P = 2 * (NP_D + NO);
+  constexpr int WAIT_LEFT = WAIT_Z < WAIT_P ? WAIT_Z : WAIT_P;
+  constexpr int DRAIN = (WAIT_LEFT - 4 + 7) / 8 + 1;      // smallest k with 8 (k - 1) + 4 >= WAIT_LEFT
+#else
   constexpr int WAIT_Z = (ZD - 1) * (NP_D + NO) + (NP_D - 4) + NO, WAIT_P = 2 * (NP_D + NO) + NO;
   constexpr int WAIT_LEFT = WAIT_Z < WAIT_P ? WAIT_Z : WAIT_P;
   constexpr int DRAIN = WAIT_LEFT >= WAIT_P ? 4 : ZD + 1;
+#endif
   static_assert(ZD >= 1 && ZD <= NBUF_H - 1, "dZ fetch distance");
 
   if (wave < 4) {
@@ -379,12 +398,20 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       const unsigned ab = lds_ld(lds_abort + (it & 1) * 4);
       next_z(it + ZD);
       next_p(it + NBUF_H - 1);
-      piece_z(wave); piece_z(4 + wave); piece_z(8 + wave); piece_z(12 + wave);
-      piece_p(2 * wave); piece_p(2 * wave + 1);
       const Rsrc sc = make_rsrc(scratch, 2048);
       const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-      buf_store(zero, sc, 0);
-      buf_store(zero, sc, 1024);
+      if (PIPE_PIECES_LATE) {
+        piece_z(wave); piece_z(4 + wave);
+        buf_store(zero, sc, 0);
+        buf_store(zero, sc, 1024);
+        piece_z(8 + wave); piece_z(12 + wave);
+        piece_p(2 * wave); piece_p(2 * wave + 1);
+      } else {
+        piece_z(wave); piece_z(4 + wave); piece_z(8 + wave); piece_z(12 + wave);
+        piece_p(2 * wave); piece_p(2 * wave + 1);
+        buf_store(zero, sc, 0);
+        buf_store(zero, sc, 1024);
+      }
       if (ab) { stop = true; break; }
       if (it == -1 && n_my > 0) { read_phases(0); decode(0); }
     }
@@ -424,26 +451,54 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
         if (ks + PF < PKS) bf[(ks + PF) % (PF + 1)] = *(const half8*)(B + (ks + PF) * 1024 + lane * 16);
         if constexpr (!HI_ONLY) dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt_lo[ks], bf[ks % (PF + 1)], dacc, 0, 0, 0);
         dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt_hi[ks], bf[ks % (PF + 1)], dacc, 0, 0, 0);
-        if (ks == 0) piece_z(wave);
-        if (ks == 2) piece_z(4 + wave);
-        if (ks == 4) piece_z(8 + wave);
-        if (ks == 6) piece_z(12 + wave);
-        if (ks == 8) piece_p(2 * wave);
-        if (ks == 10) piece_p(2 * wave + 1);
+        if (!PIPE_PIECES_LATE) {
+          if (ks == 0) piece_z(wave);
+          if (ks == 2) piece_z(4 + wave);
+          if (ks == 4) piece_z(8 + wave);
+          if (ks == 6) piece_z(12 + wave);
+          if (ks == 8) piece_p(2 * wave);
+          if (ks == 10) piece_p(2 * wave + 1);
+        }
         if (ks == 12 && decode_next) read_phases(nbuf);      // the next chunk's phases, decoded behind the epilogue
         __builtin_amdgcn_sched_barrier(0);
       }
       if (stamp) { asm volatile("" :: "v"(dacc)); s3 = __builtin_amdgcn_s_memtime(); }
       // dZ_{l-1} = dH * cos (fp16, saturating) -> ring slot, fragments 2 U, 2 U + 1 of the chunk
       half8 d0, d1;
-      dz_tile(dacc, cosc, cosc + 8, d0, d1, bs);
       const Rsrc ro = make_rsrc(out_z, SLOT);
-      buf_store(d0, ro, (2 * U) * 1024);
-      buf_store(d1, ro, (2 * U + 1) * 1024);
-      out_slot = out_slot + 1 == RING ? 0 : out_slot + 1;
-      out_z = out_slot == 0 ? ring_out : out_z + SLOT;
-      buf = nbuf;
-      if (decode_next) decode(buf);
+      if (PIPE_PIECES_LATE) {
+        // the six pieces go between the vector work of the epilogue and of the decoder (a piece beside the k-steps' LDS reads and
+        // matrix instructions holds the wave 100 - 200 clocks, here a few tens), in the order z z s s z z p p
+        piece_z(wave);
+        dz_half(dacc, 0, cosc, d0, bs);
+        __builtin_amdgcn_sched_barrier(0);
+        piece_z(4 + wave);
+        dz_half(dacc, 8, cosc + 8, d1, bs + 8);
+        __builtin_amdgcn_sched_barrier(0);
+        buf_store(d0, ro, (2 * U) * 1024);
+        buf_store(d1, ro, (2 * U + 1) * 1024);
+        piece_z(8 + wave);
+        out_slot = out_slot + 1 == RING ? 0 : out_slot + 1;
+        out_z = out_slot == 0 ? ring_out : out_z + SLOT;
+        buf = nbuf;
+        const unsigned at = lds0 + buf * BUF_HID + (16 + 2 * wave) * 1024 + voff;
+        float sn[8];
+        if (decode_next) { decode_phases(dp[0], sn, cosn); *(lds_half8*)(uintptr_t)at = to_half8(sn); }
+        __builtin_amdgcn_sched_barrier(0);
+        piece_z(12 + wave);
+        piece_p(2 * wave);
+        if (decode_next) { decode_phases(dp[1], sn, cosn + 8); *(lds_half8*)(uintptr_t)(at + 1024) = to_half8(sn); }
+        __builtin_amdgcn_sched_barrier(0);
+        piece_p(2 * wave + 1);
+      } else {
+        dz_tile(dacc, cosc, cosc + 8, d0, d1, bs);
+        buf_store(d0, ro, (2 * U) * 1024);
+        buf_store(d1, ro, (2 * U + 1) * 1024);
+        out_slot = out_slot + 1 == RING ? 0 : out_slot + 1;
+        out_z = out_slot == 0 ? ring_out : out_z + SLOT;
+        buf = nbuf;
+        if (decode_next) decode(buf);
+      }
       if (stamp) {
         const unsigned long long s4 = __builtin_amdgcn_s_memtime();
         ph[0] += s1 - s0; ph[1] += s2 - s1; ph[2] += s3 - s2; ph[3] += s4 - s3;
