@@ -396,8 +396,9 @@ def main():
 
     if rank == 0:
         fast = mode_used == 'fast'
-        FP8C = ('true' if fast else 'false') + (', true' if half else '')
-        kernel_name = f"render_fwd_kernel<{D_FILTER}, {'true' if args.mode == 'train' else 'false'}, {FP8C}>"
+        # template arguments as rocprofv3 prints them: <d_filter, stash (0 none, 1 fp16 sin + cos, 2 16-bit phases), fp8 cross terms, half>
+        stash_id = 0 if args.mode != 'train' else (2 if bwd_ms and D_FILTER == 256 else 1)
+        kernel_name = f"render_fwd_kernel<{D_FILTER}, {stash_id}, {'true' if fast else 'false'}, {'true' if half else 'false'}>"
         # dominant kernel = the fused render pass: algorithmic GEMM FLOPs of one launch / its average duration between the
         # HIP events recorded around its launches in the timed region
         achieved = rays_per_step * args.samples * flops_fwd(D_FILTER) / (render_ms * 1e-3) / 1e12
@@ -414,7 +415,7 @@ def main():
                           'what': ('dgrad (W^T as ' + ('a single fp16 image: the measured policy of ops._pipe_w_probe allows it' if pipe_single_w
                                                       else 'fp16 head + remainder: two products')
                                    + ') + wgrad of all layers but the out layer in one persistent launch; the out layer and dZ of the '
-                                   'last activation layer come from a 1.2 ms prologue kernel'),
+                                   'last activation layer come from a 0.9 ms prologue kernel'),
                           'weight_precision': f"{ops.pipe_w_mode()} -> {'single fp16' if pipe_single_w else 'fp16 head + remainder'}"
                                               + (f' (probe: worst weight tensor differs by {pipe_w_probe:.2e}, limit {ops.PIPE_W_LIMIT:.0e})'
                                                  if pipe_w_probe is not None else '')}
@@ -452,7 +453,8 @@ def main():
                      'config 3; follows an fp16-emulating oracle to 1e-4, NOT the fp32 reference)' if half else
                      ('f32 (forward: every operand split into an fp16 head and an exact remainder, head products on the fp16 '
                       'matrix cores + ' + ('block-scaled fp8 products for the two cross terms' if fast else 'fp16 products for the two cross terms')
-                      + '; backward: fp16 MFMA, W^T hi + lo; fp32 accumulate and parameters)'),
+                      + '; backward: fp16 MFMA, W^T ' + ('as a single fp16 image (measured policy)' if pipe_single_w else 'hi + lo')
+                      + '; fp32 accumulate and parameters)'),
             'data': 'synthetic',
             'config': {'workload': (f'emission render {what}, {args.res}x{args.res} frame x {args.samples} samples/ray, '
                                     f'{N_LAYERS}x{D_FILTER} sine MLP, '
