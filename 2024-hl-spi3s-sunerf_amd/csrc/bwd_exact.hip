@@ -10,11 +10,11 @@
 // per cent of its terms (bias gradients of tiny batches: tests/tools/fuzz_parity.py cases 23 / 37 / 57, 34 ... 1100 samples) keeps
 // 2^-12 x its condition number, 2e-3 ... 3e-2.  tests/tools/bias_conditioning.py reproduces those numbers on the CPU and shows
 // that fp32 summation of the bias terms alone changes little (the error sits in the chain's operands, not in the last sum).
-// At such sizes the fp16 kernels are launch-latency-bound anyway (16 K samples: 0.1 ms), so the small batches get the
-// arithmetic of the reference instead: ~1e-6 on every tensor.  Chosen by sample count in sunerf_hip/ops.py:mlp_backward.
+// So the small batches (<= 4096 samples by default: sunerf_hip/ops.py:EXACT_BACKWARD_SAMPLES) get the arithmetic of the reference
+// instead: 4e-7 ... 5e-5 on every tensor.  Chosen by sample count in sunerf_hip/ops.py:mlp_backward.
 //
-// Layer-major, plain global-memory GEMMs (one 32 x 32 output tile per wave, operands straight from L2): at <= 16 K samples
-// the whole working set (18 x N x 256 floats) is a few hundred MB at most and speed is not the point.
+// Layer-major, plain global-memory GEMMs (one 32 x 32 output tile per wave, operands straight from L2, requested a group of
+// products ahead): at these sizes the working set (18 x N x 256 floats) is 75 MB at most; 36 GEMM-sized launches per backward.
 #include "sunerf_common.h"
 #include "../../include/sunerf_hip.h"
 
@@ -51,16 +51,35 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
     k0 = (int)blockIdx.y * per;
     k1 = k0 + per < a.K ? k0 + per : a.K;
   }
+  // lane half h supplies k + h of a 2-deep product (A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31]).  The
+  // operands of GROUP products are requested together, one group ahead of the matrix instructions that consume them: with one
+  // load pair and one instruction per trip the loop ran at the latency of an L2 read per 64 matrix cycles (90 us per GEMM at
+  // 4096 samples, 36 GEMM-sized launches per backward).
+  constexpr int GROUP = 8;
   f32x16 acc = {0};
-  for (int k = k0; k < k1; k += 2) {
-    // lane half h supplies k + h of the 2-deep product (A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31])
-    const int kk = k + h;
-    const bool kok = kk < k1;
-    const int kc = kok ? kk : k0;
-    float av = pa[(long)kc * a.a_sk], bv = pb[(long)kc * a.b_sk];
-    av = (mok && kok) ? av : 0.f;
-    bv = (nok && kok) ? bv : 0.f;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+  float av[GROUP], bv[GROUP];
+  auto fetch = [&](int k, float* fa, float* fb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < GROUP; ++u) {
+      const int kk = k + 2 * u + h;
+      const bool kok = kk < k1;
+      const int kc = kok ? kk : k0;
+      const float x = pa[(long)kc * a.a_sk], y = pb[(long)kc * a.b_sk];
+      fa[u] = (mok && kok) ? x : 0.f;
+      fb[u] = (nok && kok) ? y : 0.f;
+    }
+  };
+  if (k0 < k1) fetch(k0, av, bv);
+  for (int k = k0; k < k1; k += 2 * GROUP) {
+    float an[GROUP], bn[GROUP];
+    const bool more = k + 2 * GROUP < k1;
+    if (more) fetch(k + 2 * GROUP, an, bn);
+#pragma unroll
+    for (int u = 0; u < GROUP; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < GROUP; ++u) { av[u] = an[u]; bv[u] = bn[u]; }
+    }
   }
   if (!nok) return;
 #pragma unroll
@@ -116,17 +135,29 @@ __global__ void reduce_slices_kernel(const float* partial, int slices, long coun
   dst[i] = accumulate ? dst[i] + s : s;
 }
 
-// db[o] (+)= sum over samples of dZ[s][o], accumulated in fp64 (the sum may cancel to a small fraction of its terms)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* dz, long n, int ld, int cols, float* db, int accumulate) {
-  __shared__ double part[4][64];
+// db[o] (+)= sum over samples of dZ[s][o], accumulated in fp64 (the sum may cancel to a small fraction of its terms).  One block
+// per 64 columns, 16 row groups, four independent loads in flight per thread.
+constexpr int COLSUM_GROUPS = 16;
+__global__ __launch_bounds__(64 * COLSUM_GROUPS) void colsum_kernel(const float* dz, long n, int ld, int cols, float* db, int accumulate) {
+  __shared__ double part[COLSUM_GROUPS][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-  double s = 0.0;
-  if (c < cols)
-    for (long i = q; i < n; i += 4) s += (double)dz[i * ld + c];
-  part[q][threadIdx.x & 63] = s;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (c < cols) {
+    long i = q;
+    for (; i + 3 * COLSUM_GROUPS < n; i += 4 * COLSUM_GROUPS) {
+      const float v0 = dz[i * ld + c], v1 = dz[(i + COLSUM_GROUPS) * ld + c], v2 = dz[(i + 2 * COLSUM_GROUPS) * ld + c],
+                  v3 = dz[(i + 3 * COLSUM_GROUPS) * ld + c];
+      s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+    }
+    for (; i < n; i += COLSUM_GROUPS) s0 += (double)dz[i * ld + c];
+  }
+  part[q][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (q == 0 && c < cols) {
-    const float v = (float)((part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < COLSUM_GROUPS; ++k) t += part[k][threadIdx.x];
+    const float v = (float)t;
     db[c] = accumulate ? db[c] + v : v;
   }
 }
@@ -219,7 +250,7 @@ extern "C" int sunerf_mlp_backward_exact(const float* const* weights_host, const
     const long count = (long)dz_cols * cols;
     hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ws + L.partial, K_SLICES,
                        count, grad_weights_host[i], accumulate);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((dz_cols + 63) / 64)), dim3(256), 0, st, dz, (long)N, dz_cols, dz_cols,
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((dz_cols + 63) / 64)), dim3(64 * COLSUM_GROUPS), 0, st, dz, (long)N, dz_cols, dz_cols,
                        grad_biases_host[i], accumulate);
     SUNERF_CHECK_LAUNCH();
     if (i == 0) break;
