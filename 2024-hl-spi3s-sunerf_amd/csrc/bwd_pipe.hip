@@ -3,36 +3,42 @@
 //
 // Replaces what torch.autograd derives from sunerf/model/model.py:44-57 (reference root), like sunerf_mlp_dgrad +
 // sunerf_mlp_wgrad, whose two kernels move 16.4 KB per sample of an 8 x 256 network (cos in, dZ out; H and dZ in).  Here the
-// workgroup that produces dZ_{l-1} hands it to the workgroup that consumes it through the XCD's L2, so the backward reads H
-// and cos once (8.2 KB per sample) plus the top layer's dZ (0.5 KB written once by the prologue kernel, read twice).
+// workgroup that produces dZ_{l-1} hands it to the workgroup that consumes it through the XCD's L2, and the forward leaves
+// one 16-bit PHASE per pre-activation (SUNERF_STASH_PHASE) from which this kernel recovers sin and cos: the backward reads
+// 2 bytes per activation once (4.2 KB per sample with the encoding) plus the top layer's dZ (0.5 KB, written by the prologue).
 //
 //   dW_l[j][k]  = sum_n dZ_l[j][n] H_{l-1}[k][n]        db_l[j] = sum_n dZ_l[j][n]
 //   dZ_{l-1}[k][n] = (sum_j W_l[j][k] dZ_l[j][n]) cos(Z_{l-1})[k][n]
 //
 // STAGES.  A CU cannot hold a whole layer (dW_l alone is all 256 AGPRs of its four waves), two can: stage l is a PAIR of
 // workgroups, workgroup j of it owning the 128 features J_j = [128 j, 128 j + 128) of layer l-1 -- the columns J_j of dW_l
-// (32 accumulator tiles = 128 registers per wave), the rows J_j of W_l^T (each wave keeps ITS output tile's 16 A fragments
-// in registers for the whole launch: 64 registers, + 64 for the low parts) and the fragments J_j of H_{l-1}, cos_{l-1} and
-// dZ_{l-1}.  Per 32-sample chunk it takes in dZ_l (16 KB, from the two workgroups of stage l+1), H_{l-1}[J] and cos_{l-1}[J]
-// (8 KB each, HBM, every byte read once chip-wide) by LDS-DMA, and puts out its half of dZ_{l-1} (8 KB).  A pipeline is
+// (32 accumulator tiles = 128 registers per wave), the rows J_j of W_l^T (each data-gradient wave keeps ITS output tile's 16
+// A fragments in registers for the whole launch: 64 registers, + 64 for the low parts unless HI_ONLY) and the fragments J_j of
+// the phases of layer l-1 and of dZ_{l-1}.  Per 32-sample chunk it takes in dZ_l (16 KB, from the two workgroups of stage l+1)
+// and P_{l-1}[J] (8 KB, HBM, every byte read once chip-wide) by LDS-DMA, and puts out its half of dZ_{l-1} (8 KB) and, at the
+// end of the launch, its share of db_{l-1} (fp32 sums of dH cos kept by the wave that forms the tile).  A pipeline is
 // the stages l = n_act-1 ... 1 plus the in-layer stage (dW_0 from dZ_0 and the encoding stash): 2 (n_linear - 1) workgroups,
-// all on ONE XCD so that the hand-off never leaves that XCD's L2 (plain stores stay in the L2 they were written to; the
-// consumer's LDS-DMA reads are `sc1`, i.e. served by L2 past its own stale L1).  8 x 256 network: 16 workgroups per pipeline,
-// two pipelines per XCD, 16 in all, each working through 1/16 of the chunks.
+// all on ONE XCD so that the hand-off never leaves that XCD's L2 (plain stores; the consumer's LDS-DMA reads are `sc1`, i.e.
+// served by L2 past its own stale L1).  8 x 256 network: 16 workgroups per pipeline, two pipelines per XCD, 16 in all, each
+// working through 1/16 of the chunks.
 //
-// The top stage's input, dZ of the last activation layer, and the out layer's own dW / db come from a streaming prologue
-// kernel (g_raw, cos and H of the last activation layer -> dZ_top, 512 B per sample).
+// The top stage's input, dZ of the last activation layer, that layer's db and the out layer's own dW / db come from a
+// streaming prologue kernel (g_raw and the phases of the last activation layer -> dZ_top, 512 B per sample).
 //
 // HAND-OFF.  Per link (pipeline, layer) a ring of RING chunk slots (16 KB each) in device memory and four monotonic
 // counters, each with ONE writer: prod[j] = chunks whose half producer j has stored AND drained (in-order vmcnt: known
-// NBUF iterations later), cons[j] = chunks consumer j has landed in its LDS.  A consumer may fetch chunk c once
+// DRAIN iterations later), cons[j] = chunks consumer j has landed in its LDS.  A consumer may fetch chunk c once
 // min(prod) > c; a producer may overwrite slot c % RING once min(cons) > c - RING.  The counters are polled AHEAD by LDS-DMA
-// (a 4-byte-per-lane DMA into a small LDS slot, issued NBUF-1 iterations before its value is needed and covered by the same
-// counted vmcnt wait as the chunk's data), so that a wave never waits for a flag round trip unless the partner really is
-// late; only then it falls back to a bounded spin.  Placement is CHECKED, not assumed: every workgroup publishes its XCC_ID,
+// (a 4-byte-per-lane DMA into a small LDS slot, issued PIPE_POLL_LAG iterations before its value is read), so that a wave
+// never waits for a flag round trip unless the partner really is late; only then it falls back to a bounded spin.  The ring's
+// 16 slots are shared by the age of the polled counters, the distance at which dZ is requested (PIPE_ZD) and the publication
+// delay of the outputs (DRAIN): each iteration saved there is an iteration of slack between two stages (round 4: 4 + 4 + 4 ->
+// 2 + 2 + 3; before, every stage spent 15 % of the launch on round trips for counters that were merely old).
+// Placement is CHECKED, not assumed: every workgroup publishes its XCC_ID,
 // and a class (blockIdx % 8) that does not sit on one XCD makes the whole launch give up (status word; the reduce kernel then
-// writes NaN gradients, which the optimiser's non-finite guard skips, and the host falls back to the two-kernel backward).
-// Every spin is bounded by s_memrealtime and watches the status word, so the grid always drains.
+// writes NaN gradients, which the optimiser's non-finite guard skips, raises the STICKY status word in front of the workspace,
+// and the host falls back to the two-kernel backward).  Every spin is bounded by s_memrealtime and watches the status word,
+// so the grid always drains.
 #include "grad_common.h"
 #include <mutex>
 #include <vector>
