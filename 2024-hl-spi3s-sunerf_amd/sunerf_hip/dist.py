@@ -70,18 +70,40 @@ class GradBucket:
 
 def device_identity(dev) -> tuple:
     """(host, what identifies the physical GPU behind ``dev`` in this process) -- compared across ranks by
-    :func:`ranks_share_a_device`."""
+    :func:`ranks_share_a_device`.  The device's uuid when the runtime reports a real one, else its PCI address, else the entry of
+    the visibility list (``HIP_VISIBLE_DEVICES`` / ``CUDA_VISIBLE_DEVICES``) the index stands for -- never a value that would make
+    DIFFERENT cards of one host look alike (that would silently put every rank on the slower two-kernel backward)."""
+    import os
     import socket
-    props = torch.cuda.get_device_properties(dev)
+    dev = torch.device(dev)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    props = torch.cuda.get_device_properties(index)
     ident = getattr(props, 'uuid', None)
     if ident is None or not str(ident).strip('0-'):      # (some ROCm builds report an all-zero uuid)
-        ident = tuple(getattr(props, k, None) for k in ('pci_domain_id', 'pci_bus_id', 'pci_device_id'))
+        pci = tuple(getattr(props, k, None) for k in ('pci_domain_id', 'pci_bus_id', 'pci_device_id'))
+        if all(v is not None for v in pci):
+            ident = 'pci:%s' % (pci,)
+        else:
+            ident = 'visible:%d' % index
+            for var in ('HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+                listed = [x.strip() for x in os.environ.get(var, '').split(',') if x.strip()]
+                if index < len(listed):
+                    ident = 'visible:%s' % listed[index]
+                    break
     return socket.gethostname(), str(ident)
 
 
+def identity_words(identity) -> list:
+    """Two int64 words of a hash of ``identity``: what the ranks exchange (a fixed-size tensor all-gather -- the plainest collective
+    every backend has -- instead of pickled objects)."""
+    import hashlib
+    digest = hashlib.sha256('|'.join(identity).encode()).digest()
+    return [int.from_bytes(digest[:8], 'little', signed=True), int.from_bytes(digest[8:16], 'little', signed=True)]
+
+
 def any_shared(identities) -> bool:
-    """True when two ranks of ``identities`` (one :func:`device_identity` per rank) name the same GPU."""
-    identities = list(identities)
+    """True when two ranks of ``identities`` (one :func:`device_identity`, or its hash words, per rank) name the same GPU."""
+    identities = [tuple(i) for i in identities]
     return len(set(identities)) < len(identities)
 
 
@@ -92,16 +114,18 @@ def ranks_share_a_device(dev, group=None) -> bool:
     """Collective (every rank of ``group`` must call it at the same point): do two ranks drive the same physical GPU?  The
     layer-pipelined backward needs all 256 of its workgroups resident at once, each filling a whole CU; ranks that share a card
     (CPU-style rehearsals of the multi-rank path on one GPU) would starve each other's launches into their time-outs, so they
-    take the two-kernel backward.  One all_gather_object per device, cached; called where every rank passes exactly once --
-    the construction of the optimiser / gradient bucket (``ClipAdam``, ``GradBucket``)."""
+    take the two-kernel backward.  One all-gather of two int64 words per device (on the device under RCCL, on the host under
+    gloo), cached; called where every rank passes exactly once -- the construction of the optimiser / gradient bucket
+    (``ClipAdam``, ``GradBucket``)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
         return False
     key = str(torch.device(dev))
     if key not in _shared_cache:
-        mine = device_identity(dev)
-        everyone = [None] * dist.get_world_size(group)
-        dist.all_gather_object(everyone, mine, group=group)
-        _shared_cache[key] = any_shared(everyone)
+        where = torch.device(dev) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+        mine = torch.tensor(identity_words(device_identity(dev)), dtype=torch.int64, device=where)
+        everyone = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(everyone, mine, group=group)
+        _shared_cache[key] = any_shared(t.tolist() for t in everyone)
     return _shared_cache[key]
 
 

@@ -89,3 +89,27 @@ def test_non_finite_count_in_the_bucket_tail_reaches_every_rank(tmp_path):
     mp.spawn(_worker_tail, args=(2, 29519, str(tmp_path)), nprocs=2, join=True)
     b0, b1 = torch.load(tmp_path / 'tail0.pt'), torch.load(tmp_path / 'tail1.pt')
     assert torch.equal(b0, b1) and b0[-1].item() == 1.0 and b0[0].item() == 3.0
+
+
+def _worker_shared(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, '2024-hl-spi3s-sunerf_amd'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sunerf_hip import dist as sd
+    answers = []
+    for case, ident in (('cuda:0', ('host', 'gpu%d' % rank)),          # one card per rank
+                        ('cuda:1', ('host', 'gpu7')),                  # both ranks on the same card
+                        ('cuda:2', ('host%d' % rank, 'gpu0'))):        # the same index on two hosts
+        sd.device_identity = lambda dev, ident=ident: ident
+        answers.append(sd.ranks_share_a_device(case))
+        assert sd.shared_device_known(case) == answers[-1]
+    torch.save(answers, os.path.join(out_dir, f'shared{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_shared_device_detection_is_one_tensor_all_gather(tmp_path):
+    """The collective that decides pipelined vs two-kernel backward: a fixed-size all-gather of hashed identities (on the host
+    under gloo, on the device under RCCL) -- every rank gets the same answer."""
+    mp.spawn(_worker_shared, args=(2, 29523, str(tmp_path)), nprocs=2, join=True)
+    a, b = (torch.load(os.path.join(str(tmp_path), f'shared{r}.pt')) for r in range(2))
+    assert a == b == [False, True, False]

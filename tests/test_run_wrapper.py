@@ -46,6 +46,8 @@ def test_shared_device_rule():
     assert not sd.any_shared([('a', 'gpu0'), ('a', 'gpu1'), ('b', 'gpu0')])
     assert sd.any_shared([('a', 'gpu0'), ('a', 'gpu1'), ('a', 'gpu0')])
     assert not sd.ranks_share_a_device('cuda:0') and not sd.shared_device_known('cuda:0')          # no process group: never
+    words = sd.identity_words(('a', 'gpu0'))
+    assert words == sd.identity_words(('a', 'gpu0')) != sd.identity_words(('a', 'gpu1')) and all(-2 ** 63 <= w < 2 ** 63 for w in words)
 
 
 def test_wrapper_runs_an_unchanged_script_in_every_rank(tmp_path):
