@@ -50,6 +50,9 @@ constexpr int WG = 512;                 // pipelined kernel: eight waves, two pe
 constexpr int WG_PRE = 256;             // prologue kernel
 constexpr int NBUF = 4;                 // staging buffers of the in-layer stage and of the prologue (chunks in flight: NBUF - 1)
 constexpr int NBUF_H = 5;               // ... of a hidden stage: chunk it + 4 is being fetched, chunk it + 1's phases are decoded, chunk it is consumed
+#ifndef PIPE_DMA_ON_WEIGHT
+#define PIPE_DMA_ON_WEIGHT 2            // who issues the LDS-DMA pieces of a hidden stage: see "WHO ISSUES THE PIECES" below (0: 11.48, 1: 11.38, 2: 11.04 ms, r4_pipe_ab11)
+#endif
 #ifndef PIPE_ZD
 #define PIPE_ZD 2                       // hidden stages below the top: dZ_l is requested this many iterations before it is consumed
 #endif
@@ -171,15 +174,6 @@ __device__ __forceinline__ void dz_tile(const f32x16& acc, const float* c0, cons
     bs[8 + j] += p1;
     d0[j] = (_Float16)sunerf_sat16(p0);
     d1[j] = (_Float16)sunerf_sat16(p1);
-  }
-}
-// ... one half of the tile: registers r0 .. r0 + 7
-__device__ __forceinline__ void dz_half(const f32x16& acc, int r0, const float* c, half8& d, float* bs) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float p = acc[r0 + j] * c[j];
-    bs[j] += p;
-    d[j] = (_Float16)sunerf_sat16(p);
   }
 }
 // the 32 bias sums of a tile from the 16 x 64 per-lane sums: register g on lane half h is fragment-order index
@@ -324,24 +318,31 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     else dma_piece_s<2>(nz + (size_t)f * 1024, voff, dst);
   };
   auto piece_p = [&](int f) __attribute__((always_inline)) { dma_piece_s<1>(np + (size_t)f * 1024, voff, preal ? pdst + f * 1024 : lds_dummy); };
-  // operations a data-gradient wave issues per iteration, in this order: 4 dZ pieces, 2 phase pieces, 2 output stores.  Its
-  // counted wait at the top of iteration `it` wants dZ of chunk `it` (issued in iteration it - ZD) and the phases of chunk it + 1
-  // (issued in it - 3): at most WAIT_LEFT younger operations outstanding.  The stores of iteration it - DRAIN come before all of
-  // those (vmcnt counts in issue order): chunk it - DRAIN of this stage's output is complete, which is what wave 4 publishes.
-  constexpr int NO = 2, NP_D = 6;
-#ifndef PIPE_PIECES_LATE
-#define PIPE_PIECES_LATE 0      // experiment (r4_pipe_ab10): 1 = the six pieces between the vector work behind the k-steps; 11.60 against 11.45 ms
-#endif
-#if PIPE_PIECES_LATE
-  // (pieces issued between the vector work behind the k-steps, in the order z z s s z z p p)
-  constexpr int WAIT_Z = (ZD - 1) * (NP_D + NO) + 2, WAIT_P = 2 * (NP_D + NO);
-  constexpr int WAIT_LEFT = WAIT_Z < WAIT_P ? WAIT_Z : WAIT_P;
-  constexpr int DRAIN = (WAIT_LEFT - 4 + 7) / 8 + 1;      // smallest k with 8 (k - 1) + 4 >= WAIT_LEFT
-#else
-  constexpr int WAIT_Z = (ZD - 1) * (NP_D + NO) + (NP_D - 4) + NO, WAIT_P = 2 * (NP_D + NO) + NO;
-  constexpr int WAIT_LEFT = WAIT_Z < WAIT_P ? WAIT_Z : WAIT_P;
-  constexpr int DRAIN = WAIT_LEFT >= WAIT_P ? 4 : ZD + 1;
-#endif
+  // WHO ISSUES THE PIECES (PIPE_DMA_ON_WEIGHT): 0 = the data-gradient waves, between their matrix instructions (4 dZ fragments +
+  // the 2 phase fragments of the wave's own tile each); 1 = the phase fragments by the weight-gradient waves (2 each, between
+  // THEIR matrix instructions); 2 = everything by the weight-gradient waves (4 + 2 each).  A piece holds the issuing wave for
+  // 100 - 200 clocks; behind the barrier the weight-gradient waves have ~1000 clocks to spare per chunk, the data-gradient waves
+  // -- the workgroup's long ones since they decode the phases -- none.
+  // Counted waits (vmcnt counts in issue order).  Data-gradient waves, per iteration z z z z p p s s (mode 0), z z z z s s (1),
+  // s s (2): at the top of iteration `it` dZ of chunk `it` (issued in it - ZD) and the phases of chunk it + 1 (issued in it - 3)
+  // must have landed if the wave fetched them itself: at most WAIT_LEFT younger operations outstanding; the stores of iteration
+  // it - DRAIN come before all of those: chunk it - DRAIN of this stage's output is complete, which is what wave 4 publishes.
+  // Weight-gradient waves, per iteration [flag store, poll (wave 4)] then their pieces: W_WAIT younger operations (below).
+  constexpr int NO = 2;
+  constexpr int NP_D = PIPE_DMA_ON_WEIGHT == 0 ? 6 : PIPE_DMA_ON_WEIGHT == 1 ? 4 : 0;      // pieces per data-gradient wave and iteration
+  constexpr int NP_W = 6 - NP_D;                                                           // ... per weight-gradient wave
+  constexpr int PER_D = NP_D + NO;
+  auto min3 = [](int x, int y, int z) constexpr { return x < y ? (x < z ? x : z) : (y < z ? y : z); };
+  // z's are the oldest four operations of their iteration, p's the next two, the stores the youngest two
+  constexpr int WAIT_LEFT = NP_D == 0 ? NO : min3((ZD - 1) * PER_D + (NP_D - 4) + NO, NP_D == 6 ? 2 * PER_D + NO : 63, 2 * PER_D);
+  constexpr int DRAIN = (WAIT_LEFT + PER_D - 1) / PER_D + 1;      // smallest k with WAIT_LEFT <= (k - 1) PER_D
+  // weight-gradient wave v, per iteration [flag store, poll: wave 4 only] z z z z p p (mode 2) / p p (mode 1): dZ of chunk `it`
+  // was issued in it - ZD, the phases of chunk it + 1 in it - 3, the poll read now in it - PIPE_POLL_LAG
+  auto w_wait = [min3](int per_w, bool gate_wave) constexpr {
+    return min3(NP_W == 6 ? (ZD - 1) * per_w + 2 : 63, NP_W >= 2 ? 2 * per_w : 63, gate_wave ? PIPE_POLL_LAG * per_w - 2 : 63);
+  };
+  constexpr int W_WAIT_GATE = w_wait(NP_W + 2, true), W_WAIT_REST = w_wait(NP_W, false);
+  static_assert(W_WAIT_GATE >= 0 && W_WAIT_GATE < 64 && WAIT_LEFT < 64, "vmcnt is a 6-bit counter");
   static_assert(ZD >= 1 && ZD <= NBUF_H - 1, "dZ fetch distance");
 
   if (wave < 4) {
@@ -402,22 +403,14 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       asm volatile("s_waitcnt vmcnt(%0)" :: "i"(WAIT_LEFT) : "memory");
       barrier_mem();
       const unsigned ab = lds_ld(lds_abort + (it & 1) * 4);
-      next_z(it + ZD);
-      next_p(it + NBUF_H - 1);
+      if (NP_D >= 4) next_z(it + ZD);
+      if (NP_D == 6) next_p(it + NBUF_H - 1);
       const Rsrc sc = make_rsrc(scratch, 2048);
       const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (PIPE_PIECES_LATE) {
-        piece_z(wave); piece_z(4 + wave);
-        buf_store(zero, sc, 0);
-        buf_store(zero, sc, 1024);
-        piece_z(8 + wave); piece_z(12 + wave);
-        piece_p(2 * wave); piece_p(2 * wave + 1);
-      } else {
-        piece_z(wave); piece_z(4 + wave); piece_z(8 + wave); piece_z(12 + wave);
-        piece_p(2 * wave); piece_p(2 * wave + 1);
-        buf_store(zero, sc, 0);
-        buf_store(zero, sc, 1024);
-      }
+      if (NP_D >= 4) { piece_z(wave); piece_z(4 + wave); piece_z(8 + wave); piece_z(12 + wave); }
+      if (NP_D == 6) { piece_p(2 * wave); piece_p(2 * wave + 1); }
+      buf_store(zero, sc, 0);
+      buf_store(zero, sc, 1024);
       if (ab) { stop = true; break; }
       if (it == -1 && n_my > 0) { read_phases(0); decode(0); }
     }
@@ -442,8 +435,8 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       // abort word of this iteration: requested now, looked at when the iteration's work is done (every wave leaves in the same
       // iteration, so the barrier counts still agree; what a doomed iteration computes and stores is garbage either way)
       const unsigned ab = lds_ld(lds_abort + (it & 1) * 4);
-      next_z(it + ZD);
-      next_p(it + NBUF_H - 1);
+      if (NP_D >= 4) next_z(it + ZD);
+      if (NP_D == 6) next_p(it + NBUF_H - 1);
       const char* B = smem + (size_t)buf * BUF_HID;
       f32x16 dacc = {0};
       half8 bf[PF + 1];
@@ -457,11 +450,13 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
         if (ks + PF < PKS) bf[(ks + PF) % (PF + 1)] = *(const half8*)(B + (ks + PF) * 1024 + lane * 16);
         if constexpr (!HI_ONLY) dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt_lo[ks], bf[ks % (PF + 1)], dacc, 0, 0, 0);
         dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt_hi[ks], bf[ks % (PF + 1)], dacc, 0, 0, 0);
-        if (!PIPE_PIECES_LATE) {
+        if (NP_D >= 4) {
           if (ks == 0) piece_z(wave);
           if (ks == 2) piece_z(4 + wave);
           if (ks == 4) piece_z(8 + wave);
           if (ks == 6) piece_z(12 + wave);
+        }
+        if (NP_D == 6) {
           if (ks == 8) piece_p(2 * wave);
           if (ks == 10) piece_p(2 * wave + 1);
         }
@@ -472,39 +467,13 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       // dZ_{l-1} = dH * cos (fp16, saturating) -> ring slot, fragments 2 U, 2 U + 1 of the chunk
       half8 d0, d1;
       const Rsrc ro = make_rsrc(out_z, SLOT);
-      if (PIPE_PIECES_LATE) {
-        // the six pieces go between the vector work of the epilogue and of the decoder (a piece beside the k-steps' LDS reads and
-        // matrix instructions holds the wave 100 - 200 clocks, here a few tens), in the order z z s s z z p p
-        piece_z(wave);
-        dz_half(dacc, 0, cosc, d0, bs);
-        __builtin_amdgcn_sched_barrier(0);
-        piece_z(4 + wave);
-        dz_half(dacc, 8, cosc + 8, d1, bs + 8);
-        __builtin_amdgcn_sched_barrier(0);
-        buf_store(d0, ro, (2 * U) * 1024);
-        buf_store(d1, ro, (2 * U + 1) * 1024);
-        piece_z(8 + wave);
-        out_slot = out_slot + 1 == RING ? 0 : out_slot + 1;
-        out_z = out_slot == 0 ? ring_out : out_z + SLOT;
-        buf = nbuf;
-        const unsigned at = lds0 + buf * BUF_HID + (16 + 2 * wave) * 1024 + voff;
-        float sn[8];
-        if (decode_next) { decode_phases(dp[0], sn, cosn); *(lds_half8*)(uintptr_t)at = to_half8(sn); }
-        __builtin_amdgcn_sched_barrier(0);
-        piece_z(12 + wave);
-        piece_p(2 * wave);
-        if (decode_next) { decode_phases(dp[1], sn, cosn + 8); *(lds_half8*)(uintptr_t)(at + 1024) = to_half8(sn); }
-        __builtin_amdgcn_sched_barrier(0);
-        piece_p(2 * wave + 1);
-      } else {
-        dz_tile(dacc, cosc, cosc + 8, d0, d1, bs);
-        buf_store(d0, ro, (2 * U) * 1024);
-        buf_store(d1, ro, (2 * U + 1) * 1024);
-        out_slot = out_slot + 1 == RING ? 0 : out_slot + 1;
-        out_z = out_slot == 0 ? ring_out : out_z + SLOT;
-        buf = nbuf;
-        if (decode_next) decode(buf);
-      }
+      dz_tile(dacc, cosc, cosc + 8, d0, d1, bs);
+      buf_store(d0, ro, (2 * U) * 1024);
+      buf_store(d1, ro, (2 * U + 1) * 1024);
+      out_slot = out_slot + 1 == RING ? 0 : out_slot + 1;
+      out_z = out_slot == 0 ? ring_out : out_z + SLOT;
+      buf = nbuf;
+      if (decode_next) decode(buf);
       if (stamp) {
         const unsigned long long s4 = __builtin_amdgcn_s_memtime();
         ph[0] += s1 - s0; ph[1] += s2 - s1; ph[2] += s3 - s2; ph[3] += s4 - s3;
@@ -598,7 +567,9 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   auto top = [&](int it) __attribute__((always_inline)) {
     unsigned long long sa = 0, sb = 0;
     if (stamp) sa = __builtin_amdgcn_s_memtime();
-    if (gatew) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PIPE_POLL_LAG >= 3 ? 2 * 2 : 2 * (PIPE_POLL_LAG - 1)) : "memory");      // (the poll issued PIPE_POLL_LAG iterations ago has landed)
+    // (the poll issued PIPE_POLL_LAG iterations ago and this wave's pieces of chunk `it` / phases of chunk it + 1 have landed)
+    if (gatew) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(W_WAIT_GATE) : "memory");
+    else if (NP_W) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(W_WAIT_REST) : "memory");
     if (stamp) sb = __builtin_amdgcn_s_memtime();
     barrier_mem();
     if (stamp) { t_wait = sb; t_bar = __builtin_amdgcn_s_memtime(); tw += sb - sa; tb += t_bar - sb; }
@@ -616,8 +587,18 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     }
     return ab;
   };
-  for (int it = -(NBUF_H - 1); it < 0; ++it) {      // prologue iterations: protocol only
+  // this wave's pieces of an iteration (modes 1, 2): dZ fragments v, 4 + v, 8 + v, 12 + v of chunk it + ZD, phase fragments 2 v, 2 v + 1
+  // of chunk it + NBUF_H - 1; `q` = 0 .. 5 in the order z z z z p p
+  auto w_piece = [&](int q) __attribute__((always_inline)) {
+    if (q < 4) { if (NP_W == 6) piece_z(4 * q + v); }
+    else if (NP_W >= 2) piece_p(2 * v + q - 4);
+  };
+  for (int it = -(NBUF_H - 1); it < 0; ++it) {      // prologue iterations: protocol (+ this wave's pieces of the first chunks)
     const unsigned ab = top(it);
+    if (NP_W == 6) next_z(it + ZD);
+    if (NP_W >= 2) next_p(it + NBUF_H - 1);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) w_piece(q);
     if (ab) { aborted = true; break; }
     if (gatew && it + 1 < n_my) gate(it + 1);
   }
@@ -628,6 +609,8 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     unsigned long long s0 = 0, s1 = 0, s2 = 0;
     if (stamp) s0 = __builtin_amdgcn_s_memtime();
     const unsigned ab = top(it);
+    if (NP_W == 6) next_z(it + ZD);
+    if (NP_W >= 2) next_p(it + NBUF_H - 1);
     if (stamp) s1 = __builtin_amdgcn_s_memtime();
     // operand bases of this wave's block: row tiles r0.. of the dZ fragments, column tiles c0.. of the H fragments (fp16 sin,
     // decoded in place by the data-gradient waves one iteration ago); the tile and k-step parts of the addresses are immediates
@@ -671,6 +654,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
         const half8 af = ks ? A1[i] : A0[i];
         mfma_agpr(acc[i][0], af, bf0);
         mfma_agpr(acc[i][1], af, bf1);
+        if (4 * ks + i < NP_W) w_piece(6 - NP_W + 4 * ks + i);      // one piece behind each of the first pairs of matrix instructions
         __builtin_amdgcn_sched_barrier(0);
       }
     }
