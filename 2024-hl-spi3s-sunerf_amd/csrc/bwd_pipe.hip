@@ -329,7 +329,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   // it - DRAIN come before all of those: chunk it - DRAIN of this stage's output is complete, which is what wave 4 publishes.
   // Weight-gradient waves, per iteration [flag store, poll (wave 4)] then their pieces: W_WAIT younger operations (below).
   constexpr int NO = 2;
-  constexpr int NP_D = PIPE_DMA_ON_WEIGHT == 0 ? 6 : PIPE_DMA_ON_WEIGHT == 1 ? 4 : 0;      // pieces per data-gradient wave and iteration
+  constexpr int NP_D = PIPE_DMA_ON_WEIGHT == 0 ? 6 : PIPE_DMA_ON_WEIGHT == 1 ? 4 : 0;      // (modes 2, 3: none)      // pieces per data-gradient wave and iteration
   constexpr int NP_W = 6 - NP_D;                                                           // ... per weight-gradient wave
   constexpr int PER_D = NP_D + NO;
   auto min3 = [](int x, int y, int z) constexpr { return x < y ? (x < z ? x : z) : (y < z ? y : z); };
@@ -341,7 +341,9 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   auto w_wait = [min3](int per_w, bool gate_wave) constexpr {
     return min3(NP_W == 6 ? (ZD - 1) * per_w + 2 : 63, NP_W >= 2 ? 2 * per_w : 63, gate_wave ? PIPE_POLL_LAG * per_w - 2 : 63);
   };
-  constexpr int W_WAIT_GATE = w_wait(NP_W + 2, true), W_WAIT_REST = w_wait(NP_W, false);
+  // mode 3 = mode 2 with the protocol wave relieved: wave 4 issues 1 dZ + 2 phase pieces, waves 5 - 7 five dZ + 2 phase pieces each
+  constexpr int NZ_GATE = PIPE_DMA_ON_WEIGHT == 3 ? 1 : 4, NZ_REST = PIPE_DMA_ON_WEIGHT == 3 ? 5 : 4;
+  constexpr int W_WAIT_GATE = w_wait((NP_W == 6 ? NZ_GATE + 2 : NP_W) + 2, true), W_WAIT_REST = w_wait(NP_W == 6 ? NZ_REST + 2 : NP_W, false);
   static_assert(W_WAIT_GATE >= 0 && W_WAIT_GATE < 64 && WAIT_LEFT < 64, "vmcnt is a 6-bit counter");
   static_assert(ZD >= 1 && ZD <= NBUF_H - 1, "dZ fetch distance");
 
@@ -589,7 +591,14 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   };
   // this wave's pieces of an iteration (modes 1, 2): dZ fragments v, 4 + v, 8 + v, 12 + v of chunk it + ZD, phase fragments 2 v, 2 v + 1
   // of chunk it + NBUF_H - 1; `q` = 0 .. 5 in the order z z z z p p
+  // (mode 3: q = 0 .. 6 in the order z .. z p p; wave 4 has dZ fragment 0, wave 4 + v fragments 5 v - 4 .. 5 v)
+  const int nz_mine = gatew ? NZ_GATE : NZ_REST;
   auto w_piece = [&](int q) __attribute__((always_inline)) {
+    if (PIPE_DMA_ON_WEIGHT == 3) {
+      if (q < nz_mine) piece_z(gatew ? 0 : 5 * v - 4 + q);
+      else if (q < nz_mine + 2) piece_p(2 * v + q - nz_mine);
+      return;
+    }
     if (q < 4) { if (NP_W == 6) piece_z(4 * q + v); }
     else if (NP_W >= 2) piece_p(2 * v + q - 4);
   };
@@ -598,7 +607,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     if (NP_W == 6) next_z(it + ZD);
     if (NP_W >= 2) next_p(it + NBUF_H - 1);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) w_piece(q);
+    for (int q = 0; q < 7; ++q) if (q < 6 || PIPE_DMA_ON_WEIGHT == 3) w_piece(q);
     if (ab) { aborted = true; break; }
     if (gatew && it + 1 < n_my) gate(it + 1);
   }
@@ -654,7 +663,8 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
         const half8 af = ks ? A1[i] : A0[i];
         mfma_agpr(acc[i][0], af, bf0);
         mfma_agpr(acc[i][1], af, bf1);
-        if (4 * ks + i < NP_W) w_piece(6 - NP_W + 4 * ks + i);      // one piece behind each of the first pairs of matrix instructions
+        if (PIPE_DMA_ON_WEIGHT == 3) { if (4 * ks + i < 7) w_piece(4 * ks + i); }
+        else if (4 * ks + i < NP_W) w_piece(6 - NP_W + 4 * ks + i);      // one piece behind each of the first pairs of matrix instructions
         __builtin_amdgcn_sched_barrier(0);
       }
     }
