@@ -53,6 +53,9 @@ constexpr int NBUF_H = 5;               // ... of a hidden stage: chunk it + 4 i
 #ifndef PIPE_DMA_ON_WEIGHT
 #define PIPE_DMA_ON_WEIGHT 2            // who issues the LDS-DMA pieces of a hidden stage: see "WHO ISSUES THE PIECES" below (0: 11.48, 1: 11.38, 2: 11.04 ms, r4_pipe_ab11)
 #endif
+#ifndef PIPE_DACC_VGPR
+#define PIPE_DACC_VGPR 0
+#endif
 #ifndef PIPE_ZD
 #define PIPE_ZD 2                       // hidden stages below the top: dZ_l is requested this many iterations before it is consumed
 #endif
@@ -450,8 +453,15 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
 #pragma unroll
       for (int ks = 0; ks < PKS; ++ks) {
         if (ks + PF < PKS) bf[(ks + PF) % (PF + 1)] = *(const half8*)(B + (ks + PF) * 1024 + lane * 16);
+#if PIPE_DACC_VGPR
+        // experiment: the tile in architectural VGPRs (A from the AGPR-resident W^T fragments): no v_accvgpr_read in front of the epilogue
+        if constexpr (!HI_ONLY) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(dacc) : "a"(wt_lo[ks]), "v"(bf[ks % (PF + 1)]));
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(dacc) : "a"(wt_hi[ks]), "v"(bf[ks % (PF + 1)]));
+        if (ks == PKS - 1) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(dacc));      // (matrix result -> vector read: no hazard handling for asm)
+#else
         if constexpr (!HI_ONLY) dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt_lo[ks], bf[ks % (PF + 1)], dacc, 0, 0, 0);
         dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt_hi[ks], bf[ks % (PF + 1)], dacc, 0, 0, 0);
+#endif
         if (NP_D >= 4) {
           if (ks == 0) piece_z(wave);
           if (ks == 2) piece_z(4 + wave);
