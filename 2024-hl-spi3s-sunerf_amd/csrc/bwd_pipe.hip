@@ -53,6 +53,9 @@ constexpr int NBUF_H = 5;               // ... of a hidden stage: chunk it + 4 i
 #ifndef PIPE_DMA_ON_WEIGHT
 #define PIPE_DMA_ON_WEIGHT 2            // who issues the LDS-DMA pieces of a hidden stage: see "WHO ISSUES THE PIECES" below (0: 11.48, 1: 11.38, 2: 11.04 ms, r4_pipe_ab11)
 #endif
+#ifndef PIPE_SPLIT_PROTOCOL
+#define PIPE_SPLIT_PROTOCOL 0           // experiment: wave 4 publishes, wave 5 polls and gates (the protocol wave is the longest weight-gradient wave)
+#endif
 #ifndef PIPE_DACC_VGPR
 #define PIPE_DACC_VGPR 0
 #endif
@@ -346,7 +349,15 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   };
   // mode 3 = mode 2 with the protocol wave relieved: wave 4 issues 1 dZ + 2 phase pieces, waves 5 - 7 five dZ + 2 phase pieces each
   constexpr int NZ_GATE = PIPE_DMA_ON_WEIGHT == 3 ? 1 : 4, NZ_REST = PIPE_DMA_ON_WEIGHT == 3 ? 5 : 4;
+#if PIPE_SPLIT_PROTOCOL
+  static_assert(PIPE_DMA_ON_WEIGHT == 2, "the split protocol is written for mode 2");
+  // wave 4: [flag store] z z z z p p; wave 5: [poll] z z z z p p (the poll is the OLDEST operation of its iteration)
+  constexpr int W_WAIT_PUB = min3((ZD - 1) * 7 + 2, 2 * 7, 63), W_WAIT_GATE = min3((ZD - 1) * 7 + 2, 2 * 7, PIPE_POLL_LAG * 7 - 1);
+  constexpr int W_WAIT_REST = w_wait(NP_W, false);
+#else
   constexpr int W_WAIT_GATE = w_wait((NP_W == 6 ? NZ_GATE + 2 : NP_W) + 2, true), W_WAIT_REST = w_wait(NP_W == 6 ? NZ_REST + 2 : NP_W, false);
+  constexpr int W_WAIT_PUB = W_WAIT_GATE;
+#endif
   static_assert(W_WAIT_GATE >= 0 && W_WAIT_GATE < 64 && WAIT_LEFT < 64, "vmcnt is a 6-bit counter");
   static_assert(ZD >= 1 && ZD <= NBUF_H - 1, "dZ fetch distance");
 
@@ -514,7 +525,8 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   __builtin_amdgcn_s_setprio(1);
 #endif
   const int v = wave - 4;
-  const bool gatew = v == 0;
+  const bool pubw = v == 0;                                   // publishes this workgroup's counters
+  const bool gatew = PIPE_SPLIT_PROTOCOL ? v == 1 : v == 0;   // polls the partners' counters and gates the next iteration
   // block of this wave: row tiles 4 rq .. +3 (features of dZ_l), column tiles 2 cq, 2 cq + 1 of J_j (db_l is summed where dZ_l is
   // formed: by the data-gradient waves of the stage above, or by the prologue)
   const int rq = v >> 1, cq = v & 1;
@@ -581,19 +593,21 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     if (stamp) sa = __builtin_amdgcn_s_memtime();
     // (the poll issued PIPE_POLL_LAG iterations ago and this wave's pieces of chunk `it` / phases of chunk it + 1 have landed)
     if (gatew) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(W_WAIT_GATE) : "memory");
+    else if (PIPE_SPLIT_PROTOCOL && pubw) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(W_WAIT_PUB) : "memory");
     else if (NP_W) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(W_WAIT_REST) : "memory");
     if (stamp) sb = __builtin_amdgcn_s_memtime();
     barrier_mem();
     if (stamp) { t_wait = sb; t_bar = __builtin_amdgcn_s_memtime(); tw += sb - sa; tb += t_bar - sb; }
     const unsigned ab = lds_ld(lds_abort + (it & 1) * 4);     // looked at by the caller when the iteration's work is done
-    if (gatew) {
+    if (pubw) {
       // publish: chunk `it` has landed in this workgroup (its ring slot may be overwritten); the outputs of chunk
       // it - DRAIN are in L2 (the data waves' counted waits in front of the barrier).  One store instruction, lanes 0 and 1.
-      // Then the poll whose value is read NBUF_H-1 iterations on.
       if (lane < 2) {
         const int pv = lane == 0 ? it + 1 : it - DRAIN + 1;
         st_agent(lane == 0 ? my_cons : my_prod, (unsigned)(pv > 0 ? pv : 0));
       }
+    }
+    if (gatew) {      // the poll whose value is read PIPE_POLL_LAG iterations on
       pslot = pslot + 1 == NBUF_H ? 0 : pslot + 1;
       dma_poll(poll_src, lds_poll + pslot * 256);
     }
@@ -698,7 +712,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   barrier_mem();
-  if (!aborted && gatew && lane < 2) st_agent(lane == 0 ? my_cons : my_prod, (unsigned)n_my);
+  if (!aborted && pubw && lane < 2) st_agent(lane == 0 ? my_cons : my_prod, (unsigned)n_my);
   if (a.dbg && gatew && lane == 0) {
     unsigned* d = a.dbg + (size_t)blockIdx.x * 8;
     d[0] = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_begin); d[1] = st_in[0]; d[2] = st_in[1]; d[3] = st_out[0]; d[4] = st_out[1];
