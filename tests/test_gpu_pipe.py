@@ -70,7 +70,7 @@ def _hip_grads(ops, mode, params, o, d, t, z, g_image, g_reg_const, reps=1, monk
     return [(W.cpu(), b.cpu()) for W, b in zip(gW, gb)], status
 
 
-@pytest.mark.parametrize('n_side,S,n_layers', [(6, 32, 8), (6, 40, 8), (3, 17, 8), (17, 128, 8), (9, 64, 3), (7, 96, 5), (1, 33, 8)])
+@pytest.mark.parametrize('n_side,S,n_layers', [(6, 32, 8), (6, 40, 8), (3, 17, 8), (17, 128, 8), (9, 64, 3), (7, 96, 5), (1, 33, 8), (9, 128, 8)])
 def test_pipelined_backward_matches_oracle_and_two_kernel_backward(ops, n_side, S, n_layers):
     params, o, d, t, z = _case(n_side, S, n_layers)
     g_image = torch.randn(o.shape[0]) * 1e-3
