@@ -51,13 +51,9 @@ constexpr int WG_PRE = 256;             // prologue kernel
 constexpr int NBUF = 4;                 // staging buffers of the in-layer stage and of the prologue (chunks in flight: NBUF - 1)
 constexpr int NBUF_H = 5;               // ... of a hidden stage: chunk it + 4 is being fetched, chunk it + 1's phases are decoded, chunk it is consumed
 #ifndef PIPE_DMA_ON_WEIGHT
-#define PIPE_DMA_ON_WEIGHT 2            // who issues the LDS-DMA pieces of a hidden stage: see "WHO ISSUES THE PIECES" below (0: 11.48, 1: 11.38, 2: 11.04 ms, r4_pipe_ab11)
-#endif
-#ifndef PIPE_SPLIT_PROTOCOL
-#define PIPE_SPLIT_PROTOCOL 0           // experiment: wave 4 publishes, wave 5 polls and gates (the protocol wave is the longest weight-gradient wave)
-#endif
-#ifndef PIPE_DACC_VGPR
-#define PIPE_DACC_VGPR 0
+#define PIPE_DMA_ON_WEIGHT 2            // who issues the LDS-DMA pieces of a hidden stage: see "WHO ISSUES THE PIECES" below (0: 11.48, 1: 11.38, 2: 11.04 ms, r4_pipe_ab11).
+                                        // Three more variants (3 / 7 / 7 / 7 pieces, protocol split over two waves, the data waves' tile in VGPRs) were measured slower
+                                        // and removed again: commit cafd360 has them, tools/experiments/README.md the numbers
 #endif
 #ifndef PIPE_ZD
 #define PIPE_ZD 2                       // hidden stages below the top: dZ_l is requested this many iterations before it is consumed
@@ -335,7 +331,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   // it - DRAIN come before all of those: chunk it - DRAIN of this stage's output is complete, which is what wave 4 publishes.
   // Weight-gradient waves, per iteration [flag store, poll (wave 4)] then their pieces: W_WAIT younger operations (below).
   constexpr int NO = 2;
-  constexpr int NP_D = PIPE_DMA_ON_WEIGHT == 0 ? 6 : PIPE_DMA_ON_WEIGHT == 1 ? 4 : 0;      // (modes 2, 3: none)      // pieces per data-gradient wave and iteration
+  constexpr int NP_D = PIPE_DMA_ON_WEIGHT == 0 ? 6 : PIPE_DMA_ON_WEIGHT == 1 ? 4 : 0;      // (mode 2: none)      // pieces per data-gradient wave and iteration
   constexpr int NP_W = 6 - NP_D;                                                           // ... per weight-gradient wave
   constexpr int PER_D = NP_D + NO;
   auto min3 = [](int x, int y, int z) constexpr { return x < y ? (x < z ? x : z) : (y < z ? y : z); };
@@ -347,17 +343,8 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   auto w_wait = [min3](int per_w, bool gate_wave) constexpr {
     return min3(NP_W == 6 ? (ZD - 1) * per_w + 2 : 63, NP_W >= 2 ? 2 * per_w : 63, gate_wave ? PIPE_POLL_LAG * per_w - 2 : 63);
   };
-  // mode 3 = mode 2 with the protocol wave relieved: wave 4 issues 1 dZ + 2 phase pieces, waves 5 - 7 five dZ + 2 phase pieces each
-  constexpr int NZ_GATE = PIPE_DMA_ON_WEIGHT == 3 ? 1 : 4, NZ_REST = PIPE_DMA_ON_WEIGHT == 3 ? 5 : 4;
-#if PIPE_SPLIT_PROTOCOL
-  static_assert(PIPE_DMA_ON_WEIGHT == 2, "the split protocol is written for mode 2");
-  // wave 4: [flag store] z z z z p p; wave 5: [poll] z z z z p p (the poll is the OLDEST operation of its iteration)
-  constexpr int W_WAIT_PUB = min3((ZD - 1) * 7 + 2, 2 * 7, 63), W_WAIT_GATE = min3((ZD - 1) * 7 + 2, 2 * 7, PIPE_POLL_LAG * 7 - 1);
-  constexpr int W_WAIT_REST = w_wait(NP_W, false);
-#else
-  constexpr int W_WAIT_GATE = w_wait((NP_W == 6 ? NZ_GATE + 2 : NP_W) + 2, true), W_WAIT_REST = w_wait(NP_W == 6 ? NZ_REST + 2 : NP_W, false);
-  constexpr int W_WAIT_PUB = W_WAIT_GATE;
-#endif
+  constexpr int W_WAIT_GATE = w_wait(NP_W + 2, true), W_WAIT_REST = w_wait(NP_W, false);
+
   static_assert(W_WAIT_GATE >= 0 && W_WAIT_GATE < 64 && WAIT_LEFT < 64, "vmcnt is a 6-bit counter");
   static_assert(ZD >= 1 && ZD <= NBUF_H - 1, "dZ fetch distance");
 
@@ -464,15 +451,8 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
 #pragma unroll
       for (int ks = 0; ks < PKS; ++ks) {
         if (ks + PF < PKS) bf[(ks + PF) % (PF + 1)] = *(const half8*)(B + (ks + PF) * 1024 + lane * 16);
-#if PIPE_DACC_VGPR
-        // experiment: the tile in architectural VGPRs (A from the AGPR-resident W^T fragments): no v_accvgpr_read in front of the epilogue
-        if constexpr (!HI_ONLY) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(dacc) : "a"(wt_lo[ks]), "v"(bf[ks % (PF + 1)]));
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(dacc) : "a"(wt_hi[ks]), "v"(bf[ks % (PF + 1)]));
-        if (ks == PKS - 1) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(dacc));      // (matrix result -> vector read: no hazard handling for asm)
-#else
         if constexpr (!HI_ONLY) dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt_lo[ks], bf[ks % (PF + 1)], dacc, 0, 0, 0);
         dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt_hi[ks], bf[ks % (PF + 1)], dacc, 0, 0, 0);
-#endif
         if (NP_D >= 4) {
           if (ks == 0) piece_z(wave);
           if (ks == 2) piece_z(4 + wave);
@@ -525,8 +505,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   __builtin_amdgcn_s_setprio(1);
 #endif
   const int v = wave - 4;
-  const bool pubw = v == 0;                                   // publishes this workgroup's counters
-  const bool gatew = PIPE_SPLIT_PROTOCOL ? v == 1 : v == 0;   // polls the partners' counters and gates the next iteration
+  const bool gatew = v == 0;      // the protocol wave: publishes this workgroup's counters, polls the partners', gates the next iteration
   // block of this wave: row tiles 4 rq .. +3 (features of dZ_l), column tiles 2 cq, 2 cq + 1 of J_j (db_l is summed where dZ_l is
   // formed: by the data-gradient waves of the stage above, or by the prologue)
   const int rq = v >> 1, cq = v & 1;
@@ -593,21 +572,19 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     if (stamp) sa = __builtin_amdgcn_s_memtime();
     // (the poll issued PIPE_POLL_LAG iterations ago and this wave's pieces of chunk `it` / phases of chunk it + 1 have landed)
     if (gatew) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(W_WAIT_GATE) : "memory");
-    else if (PIPE_SPLIT_PROTOCOL && pubw) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(W_WAIT_PUB) : "memory");
     else if (NP_W) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(W_WAIT_REST) : "memory");
     if (stamp) sb = __builtin_amdgcn_s_memtime();
     barrier_mem();
     if (stamp) { t_wait = sb; t_bar = __builtin_amdgcn_s_memtime(); tw += sb - sa; tb += t_bar - sb; }
     const unsigned ab = lds_ld(lds_abort + (it & 1) * 4);     // looked at by the caller when the iteration's work is done
-    if (pubw) {
+    if (gatew) {
       // publish: chunk `it` has landed in this workgroup (its ring slot may be overwritten); the outputs of chunk
       // it - DRAIN are in L2 (the data waves' counted waits in front of the barrier).  One store instruction, lanes 0 and 1.
       if (lane < 2) {
         const int pv = lane == 0 ? it + 1 : it - DRAIN + 1;
         st_agent(lane == 0 ? my_cons : my_prod, (unsigned)(pv > 0 ? pv : 0));
       }
-    }
-    if (gatew) {      // the poll whose value is read PIPE_POLL_LAG iterations on
+      // ... then the poll whose value is read PIPE_POLL_LAG iterations on
       pslot = pslot + 1 == NBUF_H ? 0 : pslot + 1;
       dma_poll(poll_src, lds_poll + pslot * 256);
     }
@@ -615,14 +592,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   };
   // this wave's pieces of an iteration (modes 1, 2): dZ fragments v, 4 + v, 8 + v, 12 + v of chunk it + ZD, phase fragments 2 v, 2 v + 1
   // of chunk it + NBUF_H - 1; `q` = 0 .. 5 in the order z z z z p p
-  // (mode 3: q = 0 .. 6 in the order z .. z p p; wave 4 has dZ fragment 0, wave 4 + v fragments 5 v - 4 .. 5 v)
-  const int nz_mine = gatew ? NZ_GATE : NZ_REST;
   auto w_piece = [&](int q) __attribute__((always_inline)) {
-    if (PIPE_DMA_ON_WEIGHT == 3) {
-      if (q < nz_mine) piece_z(gatew ? 0 : 5 * v - 4 + q);
-      else if (q < nz_mine + 2) piece_p(2 * v + q - nz_mine);
-      return;
-    }
     if (q < 4) { if (NP_W == 6) piece_z(4 * q + v); }
     else if (NP_W >= 2) piece_p(2 * v + q - 4);
   };
@@ -631,7 +601,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     if (NP_W == 6) next_z(it + ZD);
     if (NP_W >= 2) next_p(it + NBUF_H - 1);
 #pragma unroll
-    for (int q = 0; q < 7; ++q) if (q < 6 || PIPE_DMA_ON_WEIGHT == 3) w_piece(q);
+    for (int q = 0; q < 6; ++q) w_piece(q);
     if (ab) { aborted = true; break; }
     if (gatew && it + 1 < n_my) gate(it + 1);
   }
@@ -687,8 +657,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
         const half8 af = ks ? A1[i] : A0[i];
         mfma_agpr(acc[i][0], af, bf0);
         mfma_agpr(acc[i][1], af, bf1);
-        if (PIPE_DMA_ON_WEIGHT == 3) { if (4 * ks + i < 7) w_piece(4 * ks + i); }
-        else if (4 * ks + i < NP_W) w_piece(6 - NP_W + 4 * ks + i);      // one piece behind each of the first pairs of matrix instructions
+        if (4 * ks + i < NP_W) w_piece(6 - NP_W + 4 * ks + i);      // one piece behind each of the first pairs of matrix instructions
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -712,7 +681,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   barrier_mem();
-  if (!aborted && pubw && lane < 2) st_agent(lane == 0 ? my_cons : my_prod, (unsigned)n_my);
+  if (!aborted && gatew && lane < 2) st_agent(lane == 0 ? my_cons : my_prod, (unsigned)n_my);
   if (a.dbg && gatew && lane == 0) {
     unsigned* d = a.dbg + (size_t)blockIdx.x * 8;
     d[0] = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_begin); d[1] = st_in[0]; d[2] = st_in[1]; d[3] = st_out[0]; d[4] = st_out[1];
