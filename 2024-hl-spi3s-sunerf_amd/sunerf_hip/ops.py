@@ -596,12 +596,12 @@ def _pipe_flags() -> int:
 # perturbation of the weights (2^-12 per element, the same for every sample), so its effect on the weight gradients does not
 # average over the batch -- and for the same reason it can be measured on a few rays: the relative difference between the two
 # arithmetics on the first 64 rays of a batch predicts the difference on 8192 rays within 2 %
-# (tools/experiments/r4_hi_only_accuracy.py: 5.2e-4 at default initialisation, 5.1e-4 with hidden weights x 2, 7.5e-4 at x 3,
-# 9.0e-4 at x 4, against fp32 gradients: head + remainder 2.5 ... 3.4e-4 / 4.9e-4 / 7.8e-4, head alone 5.4 ... 6.0e-4 / 9.1e-4 /
-# 1.0e-3).  Every PROBE_EVERY-th parameter version (and at the first pipelined backward of a model) both arithmetics run on
-# those rays; the head alone is used while the worst weight tensor differs by at most PIPE_W_LIMIT, which keeps the gradients
-# within ~0.6 of SURVEY 8d's 1e-3.  No collective: under data parallelism every rank decides for itself (the all-reduced
-# gradient, and with it every replica, is the same on all ranks whichever arithmetic produced a rank's share).
+# (tools/experiments/r4_hi_only_accuracy.py, profiles/r4_ab/r4_hi_only_accuracy.log: probe 5.2e-4 at default initialisation, 5.0e-4 with
+# hidden weights x 2, 7.5e-4 at x 3, 8.5e-4 at x 4; against fp32 gradients: head + remainder 2.3 ... 2.8e-4 / 4.0e-4 / 6.6e-4, head
+# alone 5.3 ... 6.0e-4 / 9.2e-4 / 8.4e-4).  Every PROBE_EVERY-th parameter version (and at the first pipelined backward of a model)
+# both arithmetics run on those rays; the head alone is used while the worst weight tensor differs by at most PIPE_W_LIMIT, which
+# keeps the gradients within ~0.6 of SURVEY 8d's 1e-3.  No collective: under data parallelism every rank decides for itself (the
+# all-reduced gradient, and with it every replica, is the same on all ranks whichever arithmetic produced a rank's share).
 PIPE_W_PROBE_RAYS = 64
 PIPE_W_LIMIT = 6e-4
 
