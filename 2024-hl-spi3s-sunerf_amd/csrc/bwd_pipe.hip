@@ -120,7 +120,10 @@ __device__ __forceinline__ void dma_piece(const char* src_lane, unsigned lds_dst
 template <int POLICY>
 __device__ __forceinline__ void dma_piece_s(const char* src_uniform, unsigned voff, unsigned lds_dst) {
   const unsigned d = __builtin_amdgcn_readfirstlane(lds_dst);
-  if (POLICY == 1) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 nt" :: "v"(voff), "s"(d), "s"(src_uniform) : "memory");
+#ifndef PIPE_STREAM_BITS
+#define PIPE_STREAM_BITS "nt"      // cache policy of the read-once HBM streams (phases, top dZ); experiment: "sc0 sc1 nt", "sc1 nt", "sc0 nt"
+#endif
+  if (POLICY == 1) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 " PIPE_STREAM_BITS :: "v"(voff), "s"(d), "s"(src_uniform) : "memory");
   else if (POLICY == 2) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 sc1" :: "v"(voff), "s"(d), "s"(src_uniform) : "memory");
   else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" :: "v"(voff), "s"(d), "s"(src_uniform) : "memory");
 }
