@@ -189,8 +189,11 @@ __device__ __forceinline__ Rsrc make_rsrc(const void* p, unsigned bytes) {
 __device__ __forceinline__ void buf_store(half8 v, Rsrc r, int off) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)lane_off(), off, 0);
 }
+#ifndef SUNERF_NT_STORE_AUX
+#define SUNERF_NT_STORE_AUX 2      // cache-policy bits of the write-once streams (activation / dZ stash): 2 = nt; experiment: 0, 18 (sc1 nt), 19 (sc0 sc1 nt)
+#endif
 __device__ __forceinline__ void buf_store_nt(half8 v, Rsrc r, int off) {   // non-temporal: written once, read by another kernel
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)lane_off(), off, 2);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)lane_off(), off, SUNERF_NT_STORE_AUX);
 }
 __device__ __forceinline__ half8 buf_load(Rsrc r, int off) {
   return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off(), off, 0));
