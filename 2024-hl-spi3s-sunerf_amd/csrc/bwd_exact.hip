@@ -14,7 +14,7 @@
 // instead: 4e-7 ... 5e-5 on every tensor.  Chosen by sample count in sunerf_hip/ops.py:mlp_backward.
 //
 // Layer-major, plain global-memory GEMMs (one 32 x 32 output tile per wave, operands straight from L2, requested a group of
-// products ahead): at these sizes the working set (18 x N x 256 floats) is 75 MB at most; 36 GEMM-sized launches per backward.
+// products ahead): at these sizes the working set (18 x N x 256 floats) is 75 MB at most; 25 GEMM launches (+ 19 small ones) per backward.
 #include "sunerf_common.h"
 #include "../../include/sunerf_hip.h"
 
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
   // lane half h supplies k + h of a 2-deep product (A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31]).  The
   // operands of GROUP products are requested together, one group ahead of the matrix instructions that consume them: with one
   // load pair and one instruction per trip the loop ran at the latency of an L2 read per 64 matrix cycles (90 us per GEMM at
-  // 4096 samples, 36 GEMM-sized launches per backward).
+  // 4096 samples, 25 GEMM launches (+ 19 small ones) per backward).
   constexpr int GROUP = 8;
   f32x16 acc = {0};
   float av[GROUP], bv[GROUP];
