@@ -181,6 +181,40 @@ __device__ __forceinline__ void dz_tile(const f32x16& acc, const float* c0, cons
     d1[j] = (_Float16)sunerf_sat16(p1);
   }
 }
+#ifndef PIPE_TRIM
+#define PIPE_TRIM 1      // 1: the data-gradient waves' epilogue and decoder on explicit register PAIRS (g, g + 1): packed fp32 multiplies / adds without
+                         // the 13 v_mov per chunk that hipcc's own pairing (j, 8 + j) needed, the phase scaling as 8 packed multiplies
+#endif
+#ifndef PIPE_FP16_OVFL
+#define PIPE_FP16_OVFL 1  // 1: MODE.FP16_OVFL set in the data-gradient waves (an overflowing f16 conversion clamps to +-65504, true infinities stay: probed,
+                          // tools/probes/probe_fp16_ovfl.hip) instead of 16 v_med3 per chunk: kernel 10.90 -> 10.76 ms (r4_pipe_ab20)
+#endif
+typedef float v2f __attribute__((ext_vector_type(2)));
+// dz_tile on register pairs: p = acc * cos pairwise, fp32 bias sums, (saturating) fp16
+__device__ __forceinline__ void dz_tile_pairs(const f32x16& acc, const v2f* cs2, half8& d0, half8& d1, v2f* bs2) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const v2f a = {acc[2 * q], acc[2 * q + 1]};
+    const v2f p = a * cs2[q];
+    bs2[q] += p;
+    const float x = PIPE_FP16_OVFL ? p.x : sunerf_sat16(p.x), y = PIPE_FP16_OVFL ? p.y : sunerf_sat16(p.y);
+    if (q < 4) { d0[2 * q] = (_Float16)x; d0[2 * q + 1] = (_Float16)y; }
+    else { d1[2 * q - 8] = (_Float16)x; d1[2 * q - 7] = (_Float16)y; }
+  }
+}
+// 8 phases of one fragment -> fp16 sin (in `h`) and cos pairs
+__device__ __forceinline__ half8 decode_phases_pairs(const v4u& p, v2f* cs2) {
+  half8 h;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v2f r = {(float)(p[q] & 0xffffu), (float)(p[q] >> 16)};
+    r = r * (v2f){SUNERF_PHASE_SCALE, SUNERF_PHASE_SCALE};
+    h[2 * q] = (_Float16)__builtin_amdgcn_sinf(r.x);
+    h[2 * q + 1] = (_Float16)__builtin_amdgcn_sinf(r.y);
+    cs2[q] = (v2f){__builtin_amdgcn_cosf(r.x), __builtin_amdgcn_cosf(r.y)};
+  }
+  return h;
+}
 // the 32 bias sums of a tile from the 16 x 64 per-lane sums: register g on lane half h is fragment-order index
 // 16 (g >> 3) + 8 h + (g & 7) of the tile (grad_common.h: reduce_grads_kernel reads bias slot `lane` as that index)
 __device__ __forceinline__ void store_bias_sums(const float* bs, float* dst32) {
@@ -386,6 +420,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     // 12.2 (k-steps 1050 -> 2120 clocks), the sin half on the weight-gradient waves 12.9 (900 clocks there for half the work), all
     // DMA on the weight-gradient waves 13.5 (seven pieces in a row cost them 250 clocks each).
     float cosn[16];
+    v2f cosn2[8];      // (PIPE_TRIM) the same as pairs (g, g + 1)
     typedef __attribute__((address_space(3))) v4u lds_v4u;
     typedef __attribute__((address_space(3))) half8 lds_half8;
     v4u dp[2];
@@ -396,6 +431,12 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     };
     auto decode = [&](int b) __attribute__((always_inline)) {
       const unsigned at = lds0 + b * BUF_HID + (16 + 2 * wave) * 1024 + voff;
+      if (PIPE_TRIM) {
+        const half8 h0 = decode_phases_pairs(dp[0], cosn2), h1 = decode_phases_pairs(dp[1], cosn2 + 4);
+        *(lds_half8*)(uintptr_t)at = h0;
+        *(lds_half8*)(uintptr_t)(at + 1024) = h1;
+        return;
+      }
       float sn[16];
       decode_phases(dp[0], sn, cosn);
       decode_phases(dp[1], sn + 8, cosn + 8);
@@ -426,8 +467,12 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     char* out_z = ring_out;                        // ring slot of this iteration's output
     int out_slot = 0, buf = 0;                     // buf = it % NBUF_H
     float bs[16];                                  // this lane's share of db_{l-1}[32 U ..]: fp32 sums of dH * cos
+    v2f bs2[8];
 #pragma unroll
     for (int g = 0; g < 16; ++g) bs[g] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bs2[q] = (v2f){0.f, 0.f};
+    if (PIPE_FP16_OVFL) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);      // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL
     for (int it = 0; it < (stop ? 0 : n_my); ++it) {
       unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
       if (stamp) s0 = __builtin_amdgcn_s_memtime();
@@ -447,8 +492,11 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       f32x16 dacc = {0};
       half8 bf[PF + 1];
       float cosc[16];                              // cos of the chunk consumed now (decoded in the previous iteration)
+      v2f cosc2[8];
 #pragma unroll
       for (int g = 0; g < 16; ++g) cosc[g] = cosn[g];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) cosc2[q] = cosn2[q];
 #pragma unroll
       for (int s = 0; s < PF; ++s) bf[s] = *(const half8*)(B + s * 1024 + lane * 16);
 #pragma unroll
@@ -473,7 +521,8 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       // dZ_{l-1} = dH * cos (fp16, saturating) -> ring slot, fragments 2 U, 2 U + 1 of the chunk
       half8 d0, d1;
       const Rsrc ro = make_rsrc(out_z, SLOT);
-      dz_tile(dacc, cosc, cosc + 8, d0, d1, bs);
+      if (PIPE_TRIM) dz_tile_pairs(dacc, cosc2, d0, d1, bs2);
+      else dz_tile(dacc, cosc, cosc + 8, d0, d1, bs);
       buf_store(d0, ro, (2 * U) * 1024);
       buf_store(d1, ro, (2 * U + 1) * 1024);
       out_slot = out_slot + 1 == RING ? 0 : out_slot + 1;
@@ -491,6 +540,10 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     barrier_mem();
     // db_{l-1}, row tile U, of this pipeline: the bias column of layer l-1's partial-sum slot (every slot is written exactly once:
     // a workgroup without chunks writes its zeros)
+    if (PIPE_TRIM) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { bs[2 * q] = bs2[q].x; bs[2 * q + 1] = bs2[q].y; }
+    }
     store_bias_sums(bs, a.partial + ((size_t)(l - 1) * a.NP + P) * (PT * (PT + 1)) * 1024 + ((size_t)U * (PT + 1) + PT) * 1024);
     if (stamp && P == 0 && lane == 0) {      // timeline of iteration n_my / 2: [workgroup of the pipeline][wave][8] 64-bit shader clocks
       unsigned long long* t = (unsigned long long*)(a.dbg + 256 * 8 * 4) + (((size_t)(blockIdx.x >> 3) * 8 + wave) * 8);
