@@ -461,7 +461,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       if (ab) { stop = true; break; }
       if (it == -1 && n_my > 0) { read_phases(0); decode(0); }
     }
-    unsigned long long ph[4] = {0, 0, 0, 0};      // SUNERF_PIPE_DEBUG: shader clocks in wait / barrier / k-steps / epilogue + decode
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};      // SUNERF_PIPE_DEBUG: shader clocks in wait / barrier / k-steps / epilogue + decode; [4] products + conversion, [5] .. + stores
     unsigned long long tl[5] = {0, 0, 0, 0, 0};   //   and the stamps of iteration n_my / 2 themselves
     const bool stamp = a.dbg != nullptr;
     char* out_z = ring_out;                        // ring slot of this iteration's output
@@ -523,15 +523,18 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
       const Rsrc ro = make_rsrc(out_z, SLOT);
       if (PIPE_TRIM) dz_tile_pairs(dacc, cosc2, d0, d1, bs2);
       else dz_tile(dacc, cosc, cosc + 8, d0, d1, bs);
+      unsigned long long s3a = 0, s3b = 0;
+      if (stamp) { asm volatile("" :: "v"(d0), "v"(d1)); s3a = __builtin_amdgcn_s_memtime(); }
       buf_store(d0, ro, (2 * U) * 1024);
       buf_store(d1, ro, (2 * U + 1) * 1024);
+      if (stamp) s3b = __builtin_amdgcn_s_memtime();
       out_slot = out_slot + 1 == RING ? 0 : out_slot + 1;
       out_z = out_slot == 0 ? ring_out : out_z + SLOT;
       buf = nbuf;
       if (decode_next) decode(buf);
       if (stamp) {
         const unsigned long long s4 = __builtin_amdgcn_s_memtime();
-        ph[0] += s1 - s0; ph[1] += s2 - s1; ph[2] += s3 - s2; ph[3] += s4 - s3;
+        ph[0] += s1 - s0; ph[1] += s2 - s1; ph[2] += s3 - s2; ph[3] += s4 - s3; ph[4] += s3a - s3; ph[5] += s3b - s3;
         if (it == n_my / 2) { tl[0] = s0; tl[1] = s1; tl[2] = s2; tl[3] = s3; tl[4] = s4; }
       }
       if (ab) break;
@@ -551,7 +554,7 @@ __device__ __forceinline__ void hidden_stage(const PipeArgs& a, char* smem, int 
     }
     if (stamp && wave == 1 && lane == 0) {
       unsigned* d = a.dbg + 256 * 8 + (size_t)blockIdx.x * 8;
-      for (int k = 0; k < 4; ++k) d[k] = (unsigned)(ph[k] >> 4);
+      for (int k = 0; k < 6; ++k) d[k] = (unsigned)(ph[k] >> 4);
     }
     return;
   }

@@ -658,7 +658,7 @@ def pipe_kernel_time():
 def pipe_debug(dev=None):
     """SUNERF_PIPE_DEBUG=1: per-workgroup counters of the last pipelined launch, (8, 256, 8) int32: [0] loop ticks (100 MHz),
     fallback spins and their ticks on the input link, the same on the output link, chunks, layer, pipeline; [1] shader clocks / 16 of
-    data wave 1 per phase of its loop (wait, barrier, k-steps, epilogue); [2], [3] the same of weight waves 4 and 5 (top, operand
+    data wave 1 per phase of its loop (wait, barrier, k-steps, epilogue + decoder; of the latter: products + conversion, .. + stores); [2], [3] the same of weight waves 4 and 5 (top, operand
     reads + gate, matrix phase, counted wait, barrier); [4], [5] viewed as int64 (32, 8, 8): the stamps of iteration n / 2 of every
     wave of the workgroups of pipeline 0 (tools/pipe_check.py prints them as a timeline)."""
     for (d, _), ws in _pipe_ws.items():

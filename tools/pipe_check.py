@@ -67,7 +67,8 @@ def run(n_side, S, reps, d_filter=256, n_layers=8):
             if l > 0 and dbg.shape[0] > 1:
                 n = d[m][:, 5:6].float()
                 q = dbg[1][sel][m].float() * 16 / n
-                line += f'\n        data wave 1 clocks/chunk: wait {q[:, 0].mean():.0f} barrier {q[:, 1].mean():.0f} k-steps {q[:, 2].mean():.0f} epilogue {q[:, 3].mean():.0f}'
+                line += (f'\n        data wave 1 clocks/chunk: wait {q[:, 0].mean():.0f} barrier {q[:, 1].mean():.0f} k-steps {q[:, 2].mean():.0f} epilogue {q[:, 3].mean():.0f}'
+                         f' (products + conversion {q[:, 4].mean():.0f}, + stores {q[:, 5].mean():.0f})')
                 for w in (0, 1):
                     q = dbg[2 + w][sel][m].float() * 16 / n
                     line += f'\n        weight wave {4 + w} clocks/chunk: top {q[:, 0].mean():.0f} (wait {q[:, 3].mean():.0f} barrier {q[:, 4].mean():.0f}) reads+gate {q[:, 1].mean():.0f} matrix {q[:, 2].mean():.0f}'
