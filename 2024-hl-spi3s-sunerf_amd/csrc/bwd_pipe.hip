@@ -164,9 +164,16 @@ __device__ __forceinline__ void drain_matrix_pipe() { asm volatile("s_nop 15\n\t
 // Transposed operand read straight into FOUR CONSECUTIVE, FIXED registers (the matrix instruction's operand tuple): the two
 // ds_read_b64_tr_b16 halves of tr_issue land in separate register pairs and cost 4 v_mov per operand to join -- 48 per chunk
 // in a wave whose instruction stream is the kernel's critical path.  R0..R3: VGPR numbers, OFF: immediate byte offset.
+#ifndef PIPE_KO_WREADS
+#define PIPE_KO_WREADS 0
+#endif
+#if PIPE_KO_WREADS      // knock-out (results garbage): the weight-gradient waves' transposed operand reads are not issued
+#define TR_FIXED(R0, R1, R2, R3, OFF, var, base) asm volatile("" : "={v[" #R0 ":" #R3 "]}"(var) : "v"(base) : "memory")
+#else
 #define TR_FIXED(R0, R1, R2, R3, OFF, var, base)                                                                        \
   asm volatile("ds_read_b64_tr_b16 v[" #R0 ":" #R1 "], %1 offset:%2\n\tds_read_b64_tr_b16 v[" #R2 ":" #R3 "], %1 offset:%3" \
                : "={v[" #R0 ":" #R3 "]}"(var) : "v"(base), "i"(OFF), "i"((OFF) + 64) : "memory")
+#endif
 
 // dZ = dH * cos of one 32 x 32 tile, rounded to (saturating) fp16 for the chain -- and, before that rounding, added to this
 // lane's running bias sums `bs` (db = sum over samples of dZ, in fp32: round 4; until then the weight-gradient waves summed
