@@ -14,7 +14,7 @@
 // instead: 4e-7 ... 5e-5 on every tensor.  Chosen by sample count in sunerf_hip/ops.py:mlp_backward.
 //
 // Layer-major, plain global-memory GEMMs (one 32 x 32 output tile per wave, operands straight from L2, requested a group of
-// products ahead): at these sizes the working set (18 x N x 256 floats) is 75 MB at most; 25 GEMM launches (+ 19 small ones) per backward.
+// products ahead): at these sizes the working set (18 x N x 256 floats) is 75 MB at most; 25 GEMM launches (+ 10 small ones) per backward.
 #include "sunerf_common.h"
 #include "../../include/sunerf_hip.h"
 
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
   // lane half h supplies k + h of a 2-deep product (A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31]).  The
   // operands of GROUP products are requested together, one group ahead of the matrix instructions that consume them: with one
   // load pair and one instruction per trip the loop ran at the latency of an L2 read per 64 matrix cycles (90 us per GEMM at
-  // 4096 samples, 25 GEMM launches (+ 19 small ones) per backward).
+  // 4096 samples, 25 GEMM launches (+ 10 small ones) per backward).
   constexpr int GROUP = 8;
   f32x16 acc = {0};
   float av[GROUP], bv[GROUP];
@@ -126,19 +126,23 @@ __global__ void encode_kernel(const float* rays_o, const float* rays_d, const fl
   }
 }
 
-// dW[o][j] (+)= sum over slices of partial[slice][o][j]
-__global__ void reduce_slices_kernel(const float* partial, int slices, long count, float* dst, int accumulate) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  float s = 0.f;
-  for (int k = 0; k < slices; ++k) s += partial[(long)k * count + i];
-  dst[i] = accumulate ? dst[i] + s : s;
-}
-
-// db[o] (+)= sum over samples of dZ[s][o], accumulated in fp64 (the sum may cancel to a small fraction of its terms).  One block
-// per 64 columns, 16 row groups, four independent loads in flight per thread.
+// One launch per layer behind the weight-gradient GEMM (they were two: 44 -> 35 launches per backward):
+//   blocks [0, ceil(cols / 64)):  db[o] (+)= sum over samples of dZ[s][o], accumulated in fp64 (the sum may cancel to a small fraction
+//                                 of its terms); 64 columns per block, 16 row groups, four independent loads in flight per thread
+//   the other blocks:             dW[o][j] (+)= sum over slices of partial[slice][o][j]
 constexpr int COLSUM_GROUPS = 16;
-__global__ __launch_bounds__(64 * COLSUM_GROUPS) void colsum_kernel(const float* dz, long n, int ld, int cols, float* db, int accumulate) {
+constexpr int FINISH_THREADS = 64 * COLSUM_GROUPS;
+__global__ __launch_bounds__(FINISH_THREADS) void finish_layer_kernel(const float* partial, int slices, long count, float* dw, const float* dz,
+                                                                      long n, int ld, int cols, float* db, int accumulate) {
+  const int col_blocks = (cols + 63) / 64;
+  if ((int)blockIdx.x >= col_blocks) {
+    const long i = (long)(blockIdx.x - col_blocks) * FINISH_THREADS + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (int k = 0; k < slices; ++k) s += partial[(long)k * count + i];
+    dw[i] = accumulate ? dw[i] + s : s;
+    return;
+  }
   __shared__ double part[COLSUM_GROUPS][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -248,9 +252,8 @@ extern "C" int sunerf_mlp_backward_exact(const float* const* weights_host, const
     w.out0 = ws + L.partial; w.ldo = cols;
     if ((rc = launch_gemm<EPI_PART>(w, K_SLICES, st))) return rc;
     const long count = (long)dz_cols * cols;
-    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ws + L.partial, K_SLICES,
-                       count, grad_weights_host[i], accumulate);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((dz_cols + 63) / 64)), dim3(64 * COLSUM_GROUPS), 0, st, dz, (long)N, dz_cols, dz_cols,
+    hipLaunchKernelGGL(finish_layer_kernel, dim3((unsigned)((dz_cols + 63) / 64 + (count + FINISH_THREADS - 1) / FINISH_THREADS)),
+                       dim3(FINISH_THREADS), 0, st, ws + L.partial, K_SLICES, count, grad_weights_host[i], dz, (long)N, dz_cols, dz_cols,
                        grad_biases_host[i], accumulate);
     SUNERF_CHECK_LAUNCH();
     if (i == 0) break;
